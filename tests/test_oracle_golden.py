@@ -1,0 +1,323 @@
+"""Pin the CPU oracle against every golden vector the reference holds for this path
+ and against the reference's own F77 geometry kernels."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from fields import density, quadratic, velocity
+
+HERE = os.path.dirname(__file__)
+
+# unit_tests/UnitTestTpetra.C:86-114 (data)
+ELEM_VALS = np.array([
+    [2.0, -0.8, -0.7, -0.6, -0.5, -0.4, -0.3, -0.2],
+    [-0.8, 2.0, -0.8, -0.7, -0.6, -0.5, -0.4, -0.3],
+    [-0.7, -0.8, 2.0, -0.8, -0.7, -0.6, -0.5, -0.4],
+    [-0.6, -0.7, -0.8, 2.0, -0.8, -0.7, -0.6, -0.5],
+    [-0.5, -0.6, -0.7, -0.8, 2.0, -0.8, -0.7, -0.6],
+    [-0.4, -0.5, -0.6, -0.7, -0.8, 2.0, -0.8, -0.7],
+    [-0.3, -0.4, -0.5, -0.6, -0.7, -0.8, 2.0, -0.8],
+    [-0.2, -0.3, -0.4, -0.5, -0.6, -0.7, -0.8, 2.0]])
+LHS_VALS = np.array([
+    [2.0, -0.8, -0.6, -0.7, -0.5, -0.4, -0.2, -0.3, 0.0, 0.0, 0.0, 0.0],
+    [-0.8, 2.0, -0.7, -0.8, -0.6, -0.5, -0.3, -0.4, 0.0, 0.0, 0.0, 0.0],
+    [-0.6, -0.7, 2.0, -0.8, -0.8, -0.7, -0.5, -0.6, 0.0, 0.0, 0.0, 0.0],
+    [-0.7, -0.8, -0.8, 2.0, -0.7, -0.6, -0.4, -0.5, 0.0, 0.0, 0.0, 0.0],
+    [-0.5, -0.6, -0.8, -0.7, 4.0, -1.6, -1.2, -1.4, -0.5, -0.4, -0.2, -0.3],
+    [-0.4, -0.5, -0.7, -0.6, -1.6, 4.0, -1.4, -1.6, -0.6, -0.5, -0.3, -0.4],
+    [-0.2, -0.3, -0.5, -0.4, -1.2, -1.4, 4.0, -1.6, -0.8, -0.7, -0.5, -0.6],
+    [-0.3, -0.4, -0.6, -0.5, -1.4, -1.6, -1.6, 4.0, -0.7, -0.6, -0.4, -0.5],
+    [0.0, 0.0, 0.0, 0.0, -0.5, -0.6, -0.8, -0.7, 2.0, -0.8, -0.6, -0.7],
+    [0.0, 0.0, 0.0, 0.0, -0.4, -0.5, -0.7, -0.6, -0.8, 2.0, -0.7, -0.8],
+    [0.0, 0.0, 0.0, 0.0, -0.2, -0.3, -0.5, -0.4, -0.6, -0.7, 2.0, -0.8],
+    [0.0, 0.0, 0.0, 0.0, -0.3, -0.4, -0.6, -0.5, -0.7, -0.8, -0.8, 2.0]])
+GOLD_ROW_LENGTHS = [8, 8, 8, 8, 12, 12, 12, 12, 8, 8, 8, 8]
+
+
+def dense(rp, ci, v, ncols):
+    A = np.zeros((len(rp) - 1, ncols))
+    for i in range(len(rp) - 1):
+        A[i, ci[rp[i]:rp[i + 1]]] = v[rp[i]:rp[i + 1]]
+    return A
+
+
+def test_tpetra_basic_np1(oracle):
+    """unit_tests/UnitTestTpetra.C:230-251, np = 1: generated:1x1x2, element graph, sumInto."""
+    m = oracle.BoxMesh(2, 2, 3)
+    assert (m.hex_nodes + 1).tolist() == [[1, 2, 4, 3, 5, 6, 8, 7], [5, 6, 8, 7, 9, 10, 12, 11]]
+    ls = oracle.LinSys(1, 12)
+    ls.add_connections(m.hex_nodes)
+    ls.finalize()
+    rp, ci, _ = ls.owned_csr()
+    assert np.diff(rp).tolist() == GOLD_ROW_LENGTHS
+    for i in range(12):
+        assert np.all(np.diff(ci[rp[i]:rp[i + 1]]) > 0)  # sorted columns
+    ls.zero()
+    for e in range(2):
+        ls.sum_into(m.hex_nodes[e], np.zeros(8), ELEM_VALS)
+    rp, ci, v = ls.owned_csr()
+    np.testing.assert_allclose(dense(rp, ci, v, 12), LHS_VALS, atol=1e-9, rtol=0)
+
+
+def test_local_graph_arrays(oracle):
+    """unit_tests/UnitTestLocalGraphArrays.C:9-105."""
+    L = oracle.lib()
+    lens = np.array([i + 2 for i in range(5)], np.uintp)
+    g = L.orc_graph_create(5, lens)
+    assert g.contents.rowPointers[5] == lens.sum()
+    L.orc_graph_destroy(g)
+
+    for nd, rows, cols in [(1, [2, 3, 4], [[0, 1], [2, 3, 4], [7, 8, 6, 5]]),
+                           (3, [6, 9, 12], [[0, 3], [6, 9, 12], [21, 18, 24, 15]])]:
+        g = L.orc_graph_create(3, np.array(rows, np.uintp))
+        assert [L.orc_graph_row_length(g, i) for i in range(3)] == rows
+        for rep in range(2):
+            todo = range(3) if rep == 0 else range(2)  # second pass: duplicates for rows 0,1
+            for r in todo:
+                c = np.array(cols[r], np.int32)
+                L.orc_graph_insert_indices(g, r, len(c), c, nd)
+            nnz = sum(rows)
+            got = [g.contents.colIndices[i] for i in range(nnz)]
+            assert got == list(range(nnz))
+        L.orc_graph_destroy(g)
+
+
+def test_peclet(oracle):
+    """unit_tests/UnitTestPecletFunction.C:21-87."""
+    L = oracle.lib()
+    for pe, f in zip([0.0, 1.0, np.sqrt(5.0), 1e5], [0.0, 1.0 / 6.0, 0.5, 1.0]):
+        assert abs(L.orc_peclet_classic(5.0, 1.0, pe) - f) < 1e-6
+    c1, c2 = 5000.0, 200.0
+    for x, f in zip([-c1 - 10 * c2, c1, c1 + 10 * c2], [0.0, 0.5, 1.0]):
+        assert abs(L.orc_peclet_tanh(c1, c2, x) - f) < 1e-6
+
+
+def test_hex_scv_unit_and_grandy(oracle):
+    """unit_tests/UnitTestHexSCVDeterminant.C:67-69 (0.125 to eps) and :125-129 (det Q)."""
+    L = oracle.lib()
+    unit = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0],
+                     [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], float)
+    vol = np.zeros(8)
+    L.orc_hex_scv_det(unit, vol)
+    np.testing.assert_allclose(vol, 0.125, atol=np.finfo(float).eps, rtol=0)
+    rng = np.random.RandomState(5489)
+    for _ in range(5):
+        Q = np.diag([2.0, 2.5, 3.0]) + rng.uniform(-1, 1, (3, 3))
+        v = unit @ Q.T
+        assert abs(L.orc_hex_volume_by_triangle_facets(np.ascontiguousarray(v)) - np.linalg.det(Q)) < 1e-12
+
+
+def test_geometry_fixtures_from_reference_f77(oracle):
+    """tests/golden/hex8_geom.json was produced by the reference's own hex_scs_det /
+    hex_scv_det (tests/golden/make_hex8_geom.py).  Bit-exact."""
+    L = oracle.lib()
+    with open(os.path.join(HERE, "golden", "hex8_geom.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 5
+    for c in cases:
+        xyz = np.array(c["coords"])
+        a, v = np.zeros((12, 3)), np.zeros(8)
+        L.orc_hex_scs_det(xyz, a)
+        L.orc_hex_scv_det(xyz, v)
+        assert np.array_equal(a, np.array(c["scs_area"]))
+        assert np.array_equal(v, np.array(c["scv_vol"]))
+
+
+def test_geometry_against_live_ref(oracle):
+    r = oracle.ref_geom()
+    if r is None:
+        pytest.skip("oracle/_ref not built here")
+    L = oracle.lib()
+    m = oracle.BoxMesh(4, perturb=0.125)
+    for e in range(m.nelem):
+        c = np.ascontiguousarray(m.xyz[m.hex_nodes[e]])
+        a, v = np.zeros((12, 3)), np.zeros(8)
+        L.orc_hex_scs_det(c, a)
+        L.orc_hex_scv_det(c, v)
+        assert np.array_equal(a, oracle.ref_hex_scs_det(r, c))
+        assert np.array_equal(v, oracle.ref_hex_scv_det(r, c))
+
+
+def test_box_geometry_closed(oracle):
+    """Dual volumes sum to the box volume; interior edge area = h^2 along the edge."""
+    n = 5
+    m = oracle.BoxMesh(n)
+    vol, area = m.geometry()
+    h = 1.0 / (n - 1)
+    assert abs(vol.sum() - 1.0) < 1e-14
+    interior = 2 + n * (2 + n * 2)
+    e = np.where(m.edge_nodes[:, 0] == interior)[0]
+    np.testing.assert_allclose(area[e], np.eye(3) * h * h, atol=1e-16)
+    mp = oracle.BoxMesh(n, perturb=0.125)
+    volp, areap = mp.geometry()
+    assert abs(volp.sum() - 1.0) < 1e-13
+    assert np.abs(areap - area).max() > 1e-4
+
+
+def _cont_inputs(m, area, vol, oracle, variable_rho=True):
+    p = quadratic(m.xyz, 0)
+    dpdx = oracle.nodal_grad(m.edge_nodes, area, vol, p)
+    return dict(xyz=m.xyz, dpdx=dpdx, vel=velocity(m.xyz), p=p, rho=density(m.xyz, variable_rho))
+
+
+def test_continuity_uniform_stencil(oracle):
+    """uniform spacing h => lhsfac = -h, interior row [6h; -h x6]."""
+    n = 6
+    m = oracle.BoxMesh(n)
+    vol, area = m.geometry()
+    f = _cont_inputs(m, area, vol, oracle)
+    ls = oracle.LinSys(1, m.nnodes)
+    ls.add_connections(m.edge_nodes)
+    ls.finalize()
+    ls.zero()
+    ls.assemble_continuity(m.edge_nodes, area, f["xyz"], f["dpdx"], f["vel"], f["p"], f["rho"], 0.1)
+    rp, ci, v = ls.owned_csr()
+    h = 1.0 / (n - 1)
+    i = 2 + n * (2 + n * 2)
+    row = v[rp[i]:rp[i + 1]]
+    cols = ci[rp[i]:rp[i + 1]]
+    assert len(row) == 7
+    np.testing.assert_allclose(row[cols == i], 6 * h, rtol=1e-13)
+    np.testing.assert_allclose(row[cols != i], -h, rtol=1e-13)
+    # conservation: interior flux contributions cancel pairwise => rhs sums to ~0
+    assert abs(ls.owned_rhs().sum()) < 1e-10
+
+
+def test_edge_kernels_mirror(oracle):
+    """Swap L/R and negate A => lhs/rhs bit-identical up to the L/R relabelling."""
+    m = oracle.BoxMesh(5, perturb=0.125)
+    vol, area = m.geometry()
+    f = _cont_inputs(m, area, vol, oracle)
+    lhs, rhs = oracle.continuity_edge_coeffs(m.edge_nodes, area, f["xyz"], f["dpdx"], f["vel"],
+                                             f["p"], f["rho"], 0.1)
+    en2 = m.edge_nodes[:, ::-1].copy()
+    lhs2, rhs2 = oracle.continuity_edge_coeffs(en2, -area, f["xyz"], f["dpdx"], f["vel"], f["p"],
+                                               f["rho"], 0.1)
+    # lhs index map under relabelling: [LL,LR,RL,RR] -> [RR,RL,LR,LL]
+    np.testing.assert_allclose(lhs2[:, ::-1], lhs, rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(rhs2[:, ::-1], rhs, rtol=1e-11, atol=1e-13)
+
+
+def test_scalar_diffusion_linear_field(oracle):
+    """q = a + b.x with exact gradient: diffusion residual = 0 at interior nodes (pecfac = 0,
+    mdot = 0), also on the perturbed mesh thanks to the non-orthogonal correction."""
+    for perturb in (0.0, 0.125):
+        m = oracle.BoxMesh(6, perturb=perturb)
+        vol, area = m.geometry()
+        b = np.array([0.3, -0.7, 1.1])
+        q = 0.2 + m.xyz @ b
+        dqdx = np.tile(b, (m.nnodes, 1))
+        opts = oracle.scalar_opts()
+        ls = oracle.LinSys(1, m.nnodes)
+        ls.add_connections(m.edge_nodes)
+        ls.finalize()
+        ls.zero()
+        ls.assemble_scalar(m.edge_nodes, area, np.zeros(m.nedges), m.xyz, dqdx, velocity(m.xyz), q,
+                           np.ones(m.nnodes), 0.2 * np.ones(m.nnodes), opts)
+        rhs = ls.owned_rhs().reshape(6, 6, 6)
+        assert np.abs(rhs[1:-1, 1:-1, 1:-1]).max() < 1e-13
+
+
+def test_scalar_constant_q_divfree(oracle):
+    """Constant q: advective rhs at a node = -q * (net mdot out) ; diffusion = 0."""
+    m = oracle.BoxMesh(5, perturb=0.125)
+    vol, area = m.geometry()
+    rng = np.random.RandomState(3)
+    mdot = rng.uniform(-1, 1, m.nedges)
+    q = 0.7 * np.ones(m.nnodes)
+    opts = oracle.scalar_opts(hybrid_factor=1.0)
+    lhs, rhs = oracle.scalar_edge_coeffs(m.edge_nodes, area, mdot, m.xyz, np.zeros((m.nnodes, 3)),
+                                         velocity(m.xyz), q, np.ones(m.nnodes),
+                                         0.2 * np.ones(m.nnodes), opts)
+    np.testing.assert_allclose(rhs[:, 0], -0.7 * mdot, rtol=1e-14)
+    np.testing.assert_allclose(rhs[:, 1], +0.7 * mdot, rtol=1e-14)
+
+
+def test_dirichlet_and_reset_rows(oracle):
+    m = oracle.BoxMesh(4)
+    vol, area = m.geometry()
+    f = _cont_inputs(m, area, vol, oracle)
+    ls = oracle.LinSys(1, m.nnodes)
+    ls.add_connections(m.edge_nodes)
+    ls.finalize()
+    ls.zero()
+    ls.assemble_continuity(m.edge_nodes, area, f["xyz"], f["dpdx"], f["vel"], f["p"], f["rho"], 0.1)
+    bc = np.full(m.nnodes, 2.0)
+    ls.apply_dirichlet([0, 5], f["p"], bc)
+    ls.reset_rows([7])
+    rp, ci, v = ls.owned_csr()
+    A = dense(rp, ci, v, m.nnodes)
+    for r in (0, 5):
+        e = np.zeros(m.nnodes)
+        e[r] = 1
+        assert np.array_equal(A[r], e)
+        assert ls.owned_rhs()[r] == 2.0 - f["p"][r]
+    assert not A[7].any() and ls.owned_rhs()[7] == 0.0
+    assert A[1, 0] != 0  # columns are not eliminated (src/TpetraLinearSystem.C:1565-1575)
+
+
+def _poisson_system(oracle, n, perturb=0.0):
+    m = oracle.BoxMesh(n, perturb=perturb)
+    vol, area = m.geometry()
+    f = _cont_inputs(m, area, vol, oracle)
+    ls = oracle.LinSys(1, m.nnodes)
+    ls.add_connections(m.edge_nodes)
+    ls.finalize()
+    ls.zero()
+    ls.assemble_continuity(m.edge_nodes, area, f["xyz"], f["dpdx"], f["vel"], f["p"], f["rho"], 0.1)
+    ls.reset_rows([0])  # FixPressureAtNodeAlgorithm (src/FixPressureAtNodeAlgorithm.C:59-79)
+    ls.sum_into([0], [0.0 - f["p"][0]], [1.0])
+    return m, ls
+
+
+def test_solvers_against_scipy(oracle):
+    """Belos/Ifpack2 are not in the tree (parity unpinned): independent check of the
+    oracle's CG / GMRES against SciPy on a small pinned Poisson system."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    m, ls = _poisson_system(oracle, 6, perturb=0.125)
+    rp, ci, v = ls.owned_csr()
+    A = sp.csr_matrix((v, ci, rp), shape=(m.nnodes, m.nnodes))
+    b = ls.owned_rhs()
+    xs = spl.spsolve(A.tocsc(), b)
+    for method, pc in (("gmres", "jacobi"), ("gmres", "sgs"), ("cg", "jacobi")):
+        # the pinned row makes A non-symmetric; CG still converges here but is only
+        # compared loosely.  GMRES must reach the direct solution.
+        out = ls.solve(method, pc, tolerance=1e-12, max_iterations=400, kspace=200)
+        assert out["history"][0] == 1.0
+        if method == "gmres":
+            assert out["history"][-1] <= 1e-12
+            np.testing.assert_allclose(out["x"], xs, rtol=1e-8, atol=1e-10)
+            assert out["final_resid"] <= 1e-10 * np.linalg.norm(b) * 10
+            # implicit (Givens) residual must equal the true residual for right precond.
+            assert abs(out["final_resid"] / np.linalg.norm(b) - out["history"][-1]) < 1e-9
+    # restart bookkeeping: GMRES(5) with max_iterations 20 does exactly 20 iterations
+    out = ls.solve("gmres", "jacobi", tolerance=1e-14, max_iterations=20, kspace=5)
+    assert out["iters"] == 20 and len(out["history"]) == 21
+
+
+def test_cg_spd(oracle):
+    """CG on an SPD system (Dirichlet rows with eliminated coupling are not in the
+    reference; use the mass-shifted scalar system instead)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    m = oracle.BoxMesh(6, perturb=0.125)
+    vol, area = m.geometry()
+    q = quadratic(m.xyz, 1)
+    dqdx = oracle.nodal_grad(m.edge_nodes, area, vol, q)
+    ls = oracle.LinSys(1, m.nnodes)
+    ls.add_connections(m.edge_nodes)
+    ls.finalize()
+    ls.zero()
+    ls.assemble_scalar(m.edge_nodes, area, np.zeros(m.nedges), m.xyz, dqdx, velocity(m.xyz), q,
+                       np.ones(m.nnodes), 0.2 * np.ones(m.nnodes), oracle.scalar_opts())
+    ls.assemble_scalar_mass_be(0.9 * q, q, np.ones(m.nnodes), np.ones(m.nnodes), vol, 0.1)
+    rp, ci, v = ls.owned_csr()
+    A = sp.csr_matrix((v, ci, rp), shape=(m.nnodes, m.nnodes))
+    assert abs(A - A.T).max() < 1e-14
+    b = ls.owned_rhs()
+    out = ls.solve("cg", "jacobi", tolerance=1e-12, max_iterations=300)
+    np.testing.assert_allclose(out["x"], spl.spsolve(A.tocsc(), b), rtol=1e-9, atol=1e-12)
+    assert np.all(np.diff(out["history"]) < 0.5)  # no blow-up
