@@ -1,0 +1,243 @@
+/*
+ * nalu_gpu.h -- C ABI of the MI355X-native drop-in for gantech/Nalu's edge-based
+ * assembly + Krylov solve hot path (libnalu_gpu.so, gfx950).
+ *
+ * One opaque handle == one sierra::nalu::LinearSystem (include/LinearSystem.h:40-168 of
+ * the reference) plus the TpetraLinearSolver it owns.  Every entry point cites the
+ * reference interface it replaces (paths relative to the reference tree).  All functions
+ * return NALU_GPU_OK (0) or an error code; nalu_gpu_last_error() gives the message of the
+ * calling thread's last failure.  Pointers named *_dev are device (HBM) pointers, all
+ * others are host pointers.  numDof == 1 only (continuity and scalar transport systems).
+ *
+ * Local node numbering follows TpetraLinearSystem (src/TpetraLinearSystem.C:217-285,
+ * 1046-1074): owned nodes sorted by global id, then shared-not-owned sorted by global id,
+ * then ghosts ordered by (owner rank, global id).  Row i == owned node i; column j == local
+ * node j.
+ */
+#ifndef NALU_GPU_H
+#define NALU_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nalu_gpu_linsys nalu_gpu_linsys;
+
+enum {
+  NALU_GPU_OK = 0,
+  NALU_GPU_EINVAL = 1,      /* bad argument / shapes that do not match the graph */
+  NALU_GPU_ESTATE = 2,      /* call out of order (e.g. sumInto before finalize) */
+  NALU_GPU_EHIP = 3,        /* a HIP runtime call failed */
+  NALU_GPU_EUNSUPPORTED = 4 /* e.g. numDof != 1; mirrors "not supported" throws */
+};
+
+/* how the bulk edge kernels resolve the row conflicts of sumInto */
+enum {
+  NALU_GPU_SCATTER_ROWS = 0,    /* owner-computes row gather: deterministic, no atomics (default) */
+  NALU_GPU_SCATTER_COLORED = 1, /* edge-parallel, one launch per edge colour: deterministic */
+  NALU_GPU_SCATTER_ATOMIC = 2   /* edge-parallel, fp64 atomics on diag/rhs: NOT bit-reproducible */
+};
+
+enum { NALU_GPU_METHOD_CG = 0, NALU_GPU_METHOD_GMRES = 1 };
+enum { NALU_GPU_PRECOND_NONE = 0, NALU_GPU_PRECOND_JACOBI = 1, NALU_GPU_PRECOND_SGS = 2,
+       NALU_GPU_PRECOND_CHEBYSHEV = 3 };
+enum { NALU_GPU_PECLET_CLASSIC = 0, NALU_GPU_PECLET_TANH = 1 };
+
+const char *nalu_gpu_last_error(void);
+int nalu_gpu_version(void);
+
+/* ---- lifetime: LinearSystem::create (src/LinearSystem.C:90-109), ~EquationSystem
+ * (src/EquationSystem.C:76-77).  hip_stream: hipStream_t all work is enqueued on
+ * (NULL = the device's default stream, which is also PyTorch's default). */
+int nalu_gpu_create(nalu_gpu_linsys **out, int device, int num_dof, void *hip_stream);
+int nalu_gpu_destroy(nalu_gpu_linsys *h);
+
+/* ---- graph construction -------------------------------------------------------------
+ * beginLinearSystemConstruction (src/TpetraLinearSystem.C:162-302). gids/owner_ranks have
+ * n_owned+n_shared+n_ghost entries in local order; the ordering rules above are checked. */
+int nalu_gpu_begin_construction(nalu_gpu_linsys *h, int n_owned, int n_shared, int n_ghost,
+                                const int64_t *gids, const int *owner_ranks, int my_rank);
+/* buildNodeGraph (src/TpetraLinearSystem.C:373-395) */
+int nalu_gpu_build_node_graph(nalu_gpu_linsys *h, int64_t n_nodes, const int *node_lids);
+/* buildEdgeToNodeGraph (src/TpetraLinearSystem.C:420-425 -> :397-418 -> addConnections
+ * :355-371).  edge_nodes[2*e+{0,1}] = local ids of the edge's L and R node.  The edge
+ * index e defines the layout of every edge field passed later.  Pass every edge that
+ * touches an owned node (the locally owned ones plus the cut edges owned by neighbour
+ * ranks): owned rows are computed by their owner, so loadComplete needs no matrix export. */
+int nalu_gpu_build_edge_to_node_graph(nalu_gpu_linsys *h, int64_t n_edges, const int *edge_nodes);
+/* buildElemToNodeGraph (src/TpetraLinearSystem.C:435-440); also serves face/reduced-elem
+ * graphs, which differ only in the entity rank the caller iterates. */
+int nalu_gpu_build_elem_to_node_graph(nalu_gpu_linsys *h, int64_t n_elems, int nodes_per_elem,
+                                      const int *elem_nodes);
+/* buildDirichletNodeGraph (include/LinearSystem.h:68-75): default no-op in the reference */
+int nalu_gpu_build_dirichlet_node_graph(nalu_gpu_linsys *h, int64_t n_nodes, const int *node_lids);
+/* finalizeLinearSystem (src/TpetraLinearSystem.C:1232-1329): sorted CSR, device matrix,
+ * vectors, solver workspace. */
+int nalu_gpu_finalize(nalu_gpu_linsys *h);
+
+/* ---- views for parity dumps (Tpetra CRS layout, getLocalRowView semantics used by
+ * unit_tests/UnitTestTpetra.C:192-201 and writeToFile src/TpetraLinearSystem.C:1901-1975) */
+int nalu_gpu_get_sizes(nalu_gpu_linsys *h, int64_t *n_rows, int64_t *n_cols, int64_t *nnz);
+int nalu_gpu_get_graph(nalu_gpu_linsys *h, int64_t *row_ptr /* n_rows+1 */, int *col_idx /* nnz */);
+int nalu_gpu_get_matrix_values(nalu_gpu_linsys *h, double *values /* nnz */);
+int nalu_gpu_get_rhs(nalu_gpu_linsys *h, double *rhs /* n_rows */);
+int nalu_gpu_get_solution(nalu_gpu_linsys *h, double *x /* n_rows */);
+/* overwrite matrix values / rhs from host CSR arrays (reads a MatrixMarket dump back in) */
+int nalu_gpu_set_matrix_values(nalu_gpu_linsys *h, const double *values /* nnz */);
+int nalu_gpu_set_rhs(nalu_gpu_linsys *h, const double *rhs /* n_rows */);
+
+/* ---- assembly ------------------------------------------------------------------------
+ * zeroSystem (src/TpetraLinearSystem.C:1331-1348) */
+int nalu_gpu_zero_system(nalu_gpu_linsys *h);
+/* sumInto, vector overload (src/TpetraLinearSystem.C:1454-1507 + sum_into_row :1350-1385):
+ * host slow path for nodal / BC algorithms. lhs is n_obj x n_obj row-major.  Rows of
+ * non-owned nodes and columns outside the graph are skipped silently, as there. */
+int nalu_gpu_sum_into(nalu_gpu_linsys *h, int n_obj, const int *node_lids, const double *rhs,
+                      const double *lhs);
+
+typedef struct { const double *x, *y, *z; } nalu_gpu_vec3; /* SoA device arrays */
+
+/* AssembleContinuityEdgeSolverAlgorithm (src/AssembleContinuityEdgeSolverAlgorithm.C:52-59) */
+typedef struct {
+  nalu_gpu_vec3 coordinates; /* node */
+  nalu_gpu_vec3 dpdx;        /* node, "dpdx" */
+  nalu_gpu_vec3 velocity;    /* node, "velocity" or "velocity_rtm" */
+  const double *pressure;    /* node */
+  const double *density;     /* node, state NP1 */
+  nalu_gpu_vec3 edge_area;   /* edge, "edge_area_vector" */
+} nalu_gpu_continuity_fields;
+/* AssembleContinuityEdgeSolverAlgorithm::execute (:74-209) for every edge of the graph */
+int nalu_gpu_assemble_continuity_edges(nalu_gpu_linsys *h, const nalu_gpu_continuity_fields *f_dev,
+                                       double dt, double gamma1, double noc_fac,
+                                       double interp_together, int scatter_mode);
+
+/* AssembleScalarEdgeSolverAlgorithm (src/AssembleScalarEdgeSolverAlgorithm.C:56-67) */
+typedef struct {
+  nalu_gpu_vec3 coordinates;
+  nalu_gpu_vec3 dqdx;
+  nalu_gpu_vec3 velocity;
+  const double *scalar_q;        /* state NP1 */
+  const double *density;         /* state NP1 */
+  const double *diff_flux_coeff;
+  nalu_gpu_vec3 edge_area;
+  const double *mass_flow_rate;  /* edge */
+} nalu_gpu_scalar_fields;
+/* realm_.get_alpha_factor / get_alpha_upw_factor / get_upw_factor / primitive_uses_limiter
+ * (:102-106) and EquationSystem::create_peclet_function (include/EquationSystem.h:305-322) */
+typedef struct {
+  double alpha, alpha_upw, ho_upwind;
+  int use_limiter;
+  int peclet_kind;       /* NALU_GPU_PECLET_* */
+  double hybrid_factor;  /* classic: hf */
+  double tanh_c1, tanh_c2;
+} nalu_gpu_scalar_options;
+/* AssembleScalarEdgeSolverAlgorithm::execute (:90-315) */
+int nalu_gpu_assemble_scalar_edges(nalu_gpu_linsys *h, const nalu_gpu_scalar_fields *f_dev,
+                                   const nalu_gpu_scalar_options *opts, int scatter_mode);
+/* AssembleNodeSolverAlgorithm::execute (src/AssembleNodeSolverAlgorithm.C:57-112) with
+ * ScalarMassBackwardEulerNodeSuppAlg::node_execute (src/ScalarMassBackwardEulerNodeSuppAlg.C:65-80)
+ * over all owned nodes, in bulk. */
+int nalu_gpu_assemble_scalar_mass_be(nalu_gpu_linsys *h, const double *q_n_dev,
+                                     const double *q_np1_dev, const double *rho_n_dev,
+                                     const double *rho_np1_dev, const double *dual_volume_dev,
+                                     double dt);
+/* applyDirichletBCs (src/TpetraLinearSystem.C:1509-1586): node list on the host, fields on
+ * the device indexed by local node id. */
+int nalu_gpu_apply_dirichlet(nalu_gpu_linsys *h, int64_t n_nodes, const int *node_lids,
+                             const double *solution_dev, const double *bc_values_dev);
+/* resetRows (src/TpetraLinearSystem.C:1638-1684) */
+int nalu_gpu_reset_rows(nalu_gpu_linsys *h, int64_t n_nodes, const int *node_lids);
+/* loadComplete (src/TpetraLinearSystem.C:1686-1707) */
+int nalu_gpu_load_complete(nalu_gpu_linsys *h);
+
+/* ---- solve ---------------------------------------------------------------------------
+ * TpetraLinearSolverConfig::load (src/LinearSolverConfig.C:34-107; defaults
+ * include/LinearSolverConfig.h:70-80): tolerance 1e-4, max_iterations 50, kspace 50. */
+typedef struct {
+  int method;         /* NALU_GPU_METHOD_* */
+  int precond;        /* NALU_GPU_PRECOND_* */
+  double tolerance;   /* "Convergence Tolerance" (final_tolerance on the last outer iter) */
+  int max_iterations; /* "Maximum Iterations" */
+  int kspace;         /* "Num Blocks"; Maximum Restarts = max(1, max_iterations/kspace) */
+  int check_every;    /* host polls the device convergence flag every this many iterations
+                         (0 = default 10); does not change results */
+} nalu_gpu_solver_config;
+typedef struct {
+  int iters;              /* solver_->getNumIters() (src/LinearSolver.C:226) */
+  double final_resid;     /* ||A x - b||_2 (src/LinearSolver.C:153-178,227) */
+  double rhs_norm2;       /* ownedRhs_->norm2() (src/TpetraLinearSystem.C:1756), global */
+  double precond_seconds; /* timerPrecond_ (src/LinearSolver.C:195-211) */
+  double solve_seconds;
+  int history_len;
+} nalu_gpu_solve_info;
+/* TpetraLinearSystem::solve (src/TpetraLinearSystem.C:1709-1780) -> TpetraLinearSolver::solve
+ * (src/LinearSolver.C:181-230).  x0 = 0.  x_out_dev (n_owned+n_shared+n_ghost doubles, may be
+ * NULL) receives the solution with shared/ghost entries synchronised (copy_tpetra_to_stk +
+ * sync_field).  history[k] = relative residual after iteration k (history[0] = 1): what
+ * Belos prints with output_level > 0 (src/LinearSolverConfig.C:56-64). */
+int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, double *x_out_dev,
+                   nalu_gpu_solve_info *info, double *history, int history_cap);
+
+/* ---- building blocks exposed for measurement and parity (Tpetra call sites:
+ * matrix_->apply src/LinearSolver.C:164, update :166, norm2 :172) */
+int nalu_gpu_spmv(nalu_gpu_linsys *h, const double *x_dev /* n_cols */, double *y_dev /* n_rows */);
+int nalu_gpu_dot(nalu_gpu_linsys *h, const double *a_dev, const double *b_dev, int64_t n, double *out);
+int nalu_gpu_axpy(nalu_gpu_linsys *h, double alpha, const double *x_dev, double *y_dev, int64_t n);
+int nalu_gpu_norm2(nalu_gpu_linsys *h, const double *a_dev, int64_t n, double *out);
+
+/* ---- adjacent edge algorithms ---------------------------------
+ * ComputeMdotEdgeAlgorithm::execute (src/ComputeMdotEdgeAlgorithm.C:67-174) */
+int nalu_gpu_compute_mdot_edges(nalu_gpu_linsys *h, const nalu_gpu_continuity_fields *f_dev,
+                                double dt, double gamma1, double noc_fac, double interp_together,
+                                double *mdot_dev /* n_edges */);
+/* AssembleNodalGradEdgeAlgorithm::execute + driver zeroing
+ * (src/AssembleNodalGradEdgeAlgorithm.C:54-118, src/AssembleNodalGradAlgorithmDriver.C:59-123),
+ * owned nodes only; ghost/shared entries are left for the caller's halo exchange. */
+int nalu_gpu_nodal_grad_edges(nalu_gpu_linsys *h, nalu_gpu_vec3 edge_area_dev,
+                              const double *dual_volume_dev, const double *q_dev,
+                              double *gx_dev, double *gy_dev, double *gz_dev);
+
+/* ---- multi-GPU plumbing (Tpetra Import/Export + all-reduce equivalents) ----------------
+ * The library packs/unpacks and reduces on the device; moving bytes between GPUs is the
+ * host's job (RCCL through torch.distributed, or ncclSend/Recv from a C++ host).
+ * Halo plan: for neighbour p, send_lids[send_offsets[p]..send_offsets[p+1]) are owned rows
+ * whose values go to p; received values land in columns n_owned+recv_offsets[p].. in
+ * order (shared-not-owned and ghost columns are contiguous per owner by construction). */
+int nalu_gpu_set_halo_plan(nalu_gpu_linsys *h, int n_neighbors, const int *neighbor_ranks,
+                           const int *send_offsets, const int *send_lids,
+                           const int *recv_offsets);
+typedef struct {
+  void *ctx;
+  /* in-place sum over ranks of count doubles at the handle's reduce buffer */
+  int (*allreduce_sum)(void *ctx, int count, void *hip_stream);
+  /* move the packed send buffer to the neighbours' receive buffers (begin may return
+   * before completion; end makes hip_stream wait for the received data) */
+  int (*exchange_begin)(void *ctx, void *hip_stream);
+  int (*exchange_end)(void *ctx, void *hip_stream);
+} nalu_gpu_comm;
+int nalu_gpu_set_comm(nalu_gpu_linsys *h, const nalu_gpu_comm *comm);
+int nalu_gpu_get_comm_buffers(nalu_gpu_linsys *h, double **send_buf_dev, int64_t *send_count,
+                              double **recv_buf_dev, int64_t *recv_count,
+                              double **reduce_buf_dev, int *reduce_capacity);
+/* owner -> sharer/ghost update of one column-space vector (stk::mesh::copy_owned_to_shared,
+ * src/LinearSystem.C:111-116; Tpetra Import inside CrsMatrix::apply) */
+int nalu_gpu_halo_exchange(nalu_gpu_linsys *h, double *vec_dev /* n_cols */);
+
+/* ---- timers: EquationSystem's buckets (src/EquationSystem.C:270-292) measured with HIP
+ * events on the handle's stream. */
+enum {
+  NALU_GPU_T_ZERO = 0, NALU_GPU_T_ASSEMBLE_EDGES = 1, NALU_GPU_T_SPMV = 2,
+  NALU_GPU_T_SOLVE = 3, NALU_GPU_T_PRECOND = 4, NALU_GPU_T_BC = 5, NALU_GPU_T_COUNT = 6
+};
+int nalu_gpu_set_profiling(nalu_gpu_linsys *h, int enabled);
+/* synchronises the stream, then returns accumulated device ms and launch count */
+int nalu_gpu_get_timer(nalu_gpu_linsys *h, int which, double *total_ms, int64_t *count);
+int nalu_gpu_reset_timers(nalu_gpu_linsys *h);
+int nalu_gpu_synchronize(nalu_gpu_linsys *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

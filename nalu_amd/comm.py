@@ -1,0 +1,86 @@
+"""Multi-GPU plumbing: the three callbacks of nalu_gpu_comm implemented with
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPU node; "gloo" in tests).
+
+The library packs boundary values into its send buffer and reduces dot products into its
+reduce buffer on the device; this module only moves those bytes between ranks:
+  * halo exchange  = the Tpetra Import inside CrsMatrix::apply (src/LinearSolver.C:164,224)
+                     and stk::mesh::copy_owned_to_shared (src/LinearSystem.C:115)
+  * all-reduce     = Tpetra dot / norm2 (src/LinearSolver.C:172, src/TpetraLinearSystem.C:1756)
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+
+class _DevArray:
+    """Expose a raw device pointer through __cuda_array_interface__ so torch can wrap it."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+def wrap_device(ptr, n, device):
+    if n == 0 or not ptr:
+        return torch.zeros(0, dtype=torch.float64, device=device)
+    return torch.as_tensor(_DevArray(ptr, n), device=device)
+
+
+class TorchComm:
+    """Owns the ctypes callback struct for one GpuLinearSystem."""
+
+    def __init__(self, linsys, neighbors, send_offsets, recv_offsets, device, group=None):
+        self.group = group
+        self.device = device
+        self.neighbors = [int(p) for p in neighbors]
+        self.so = [int(v) for v in send_offsets]
+        self.ro = [int(v) for v in recv_offsets]
+        (sb, sc), (rb, rc), (red, cap) = linsys.comm_buffers()
+        self.send = wrap_device(sb, sc, device)
+        self.recv = wrap_device(rb, rc, device)
+        self.reduce = wrap_device(red, cap, device)
+        self.pending = []
+        self.errors = []
+        self._ar = L.ALLREDUCE_FN(self._allreduce)
+        self._xb = L.EXCHANGE_FN(self._exchange_begin)
+        self._xe = L.EXCHANGE_FN(self._exchange_end)
+        self.struct = L.Comm(None, self._ar, self._xb, self._xe)
+        linsys.set_comm(self.struct)
+
+    # callbacks must never raise through ctypes: record and return non-zero
+    def _allreduce(self, ctx, count, stream):
+        try:
+            dist.all_reduce(self.reduce[:count], op=dist.ReduceOp.SUM, group=self.group)
+            return 0
+        except Exception as e:  # pragma: no cover
+            self.errors.append(repr(e))
+            return 1
+
+    def _exchange_begin(self, ctx, stream):
+        try:
+            ops = []
+            for n, p in enumerate(self.neighbors):
+                if self.so[n + 1] > self.so[n]:
+                    ops.append(dist.P2POp(dist.isend, self.send[self.so[n]:self.so[n + 1]], p,
+                                          group=self.group))
+                if self.ro[n + 1] > self.ro[n]:
+                    ops.append(dist.P2POp(dist.irecv, self.recv[self.ro[n]:self.ro[n + 1]], p,
+                                          group=self.group))
+            self.pending = dist.batch_isend_irecv(ops) if ops else []
+            return 0
+        except Exception as e:  # pragma: no cover
+            self.errors.append(repr(e))
+            return 1
+
+    def _exchange_end(self, ctx, stream):
+        try:
+            for w in self.pending:
+                w.wait()
+            self.pending = []
+            return 0
+        except Exception as e:  # pragma: no cover
+            self.errors.append(repr(e))
+            return 1

@@ -1,0 +1,487 @@
+// assemble.hip -- bulk edge assembly kernels (continuity, scalar transport), the adjacent
+// edge algorithms (mdot, nodal gradient) and the nodal mass term, for gfx950.
+//
+// Every kernel here is HBM-bound gather/scatter work in fp64: no MFMA.  The per-edge
+// arithmetic is written operation by operation like the reference loops so that, with FP
+// contraction off, results are bit-identical to the CPU oracle on identically ordered
+// meshes.
+#include "internal.hpp"
+
+using namespace nalu_gpu;
+
+namespace {
+
+// ------------------------------------------------------------------ continuity
+struct ContParams {
+  nalu_gpu_continuity_fields f;
+  double tau, noc, interp;
+};
+
+struct ContOp {
+  using Params = ContParams;
+  struct Node {
+    double x[3], g[3], u[3], p, rho;
+  };
+  __device__ static __forceinline__ Node load(const Params &P, int n)
+  {
+    Node a;
+    a.x[0] = P.f.coordinates.x[n]; a.x[1] = P.f.coordinates.y[n]; a.x[2] = P.f.coordinates.z[n];
+    a.g[0] = P.f.dpdx.x[n]; a.g[1] = P.f.dpdx.y[n]; a.g[2] = P.f.dpdx.z[n];
+    a.u[0] = P.f.velocity.x[n]; a.u[1] = P.f.velocity.y[n]; a.u[2] = P.f.velocity.z[n];
+    a.p = P.f.pressure[n];
+    a.rho = P.f.density[n];
+    return a;
+  }
+  // src/AssembleContinuityEdgeSolverAlgorithm.C:163-203; returns tmdot
+  __device__ static __forceinline__ double flux(const Params &P, long long e, const Node &L,
+                                                const Node &R, double &lhsfac)
+  {
+    const double av[3] = {P.f.edge_area.x[e], P.f.edge_area.y[e], P.f.edge_area.z[e]};
+    const double om_interp = 1.0 - P.interp;
+    double axdx = 0.0, asq = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double axj = av[j];
+      const double dxj = R.x[j] - L.x[j];
+      asq += axj * axj;
+      axdx += axj * dxj;
+    }
+    const double inv_axdx = 1.0 / axdx;
+    const double rhoIp = 0.5 * (R.rho + L.rho);
+    double tmdot = -P.tau * (R.p - L.p) * asq * inv_axdx;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double axj = av[j];
+      const double dxj = R.x[j] - L.x[j];
+      const double kxj = axj - asq * inv_axdx * dxj;
+      const double rhoUjIp = 0.5 * (R.rho * R.u[j] + L.rho * L.u[j]);
+      const double ujIp = 0.5 * (R.u[j] + L.u[j]);
+      const double GjIp = 0.5 * (R.g[j] + L.g[j]);
+      tmdot += (P.interp * rhoUjIp + om_interp * rhoIp * ujIp + P.tau * GjIp) * axj -
+               P.tau * kxj * GjIp * P.noc;
+    }
+    lhsfac = -asq * inv_axdx;
+    return tmdot;
+  }
+  __device__ static __forceinline__ void edge(const Params &P, long long e, const Node &L,
+                                              const Node &R, double lhs[4], double rhs[2])
+  {
+    double lhsfac;
+    const double tmdot = flux(P, e, L, R, lhsfac);
+    lhs[0] = -lhsfac;
+    lhs[1] = +lhsfac;
+    rhs[0] = -tmdot / P.tau;
+    lhs[2] = +lhsfac;
+    lhs[3] = -lhsfac;
+    rhs[1] = tmdot / P.tau;
+  }
+};
+
+// ---------------------------------------------------------------------- scalar
+struct ScalParams {
+  nalu_gpu_scalar_fields f;
+  nalu_gpu_scalar_options o;
+};
+
+struct ScalOp {
+  using Params = ScalParams;
+  struct Node {
+    double x[3], g[3], u[3], q, rho, gam;
+  };
+  __device__ static __forceinline__ Node load(const Params &P, int n)
+  {
+    Node a;
+    a.x[0] = P.f.coordinates.x[n]; a.x[1] = P.f.coordinates.y[n]; a.x[2] = P.f.coordinates.z[n];
+    a.g[0] = P.f.dqdx.x[n]; a.g[1] = P.f.dqdx.y[n]; a.g[2] = P.f.dqdx.z[n];
+    a.u[0] = P.f.velocity.x[n]; a.u[1] = P.f.velocity.y[n]; a.u[2] = P.f.velocity.z[n];
+    a.q = P.f.scalar_q[n];
+    a.rho = P.f.density[n];
+    a.gam = P.f.diff_flux_coeff[n];
+    return a;
+  }
+  // src/AssembleScalarEdgeSolverAlgorithm.C:320-329
+  __device__ static __forceinline__ double van_leer(double dqm, double dqp, double small)
+  {
+    return (2.0 * (dqm * dqp + fabs(dqm * dqp))) / ((dqm + dqp) * (dqm + dqp) + small);
+  }
+  // src/AssembleScalarEdgeSolverAlgorithm.C:199-309
+  __device__ static __forceinline__ void edge(const Params &P, long long e, const Node &L,
+                                              const Node &R, double lhs[4], double rhs[2])
+  {
+    const double small = 1.0e-16;
+    const double av[3] = {P.f.edge_area.x[e], P.f.edge_area.y[e], P.f.edge_area.z[e]};
+    const double tmdot = P.f.mass_flow_rate[e];
+    const double alpha = P.o.alpha, alphaUpw = P.o.alpha_upw, hoUpwind = P.o.ho_upwind;
+    const double om_alpha = 1.0 - alpha, om_alphaUpw = 1.0 - alphaUpw;
+    double axdx = 0.0, asq = 0.0, udotx = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double axj = av[j];
+      const double dxj = R.x[j] - L.x[j];
+      asq += axj * axj;
+      axdx += axj * dxj;
+      udotx += 0.5 * dxj * (L.u[j] + R.u[j]);
+    }
+    const double inv_axdx = 1.0 / axdx;
+    const double viscIp = 0.5 * (L.gam + R.gam);
+    const double diffIp = 0.5 * (L.gam / L.rho + R.gam / R.rho);
+    const double pe = fabs(udotx) / (diffIp + small);
+    double pecfac;
+    if (P.o.peclet_kind == NALU_GPU_PECLET_CLASSIC) {
+      // src/PecletFunction.C:70-75 (A is hard-wired to 5.0 there)
+      const double modPeclet = P.o.hybrid_factor * pe;
+      pecfac = modPeclet * modPeclet / (5.0 + modPeclet * modPeclet);
+    } else {
+      // src/PecletFunction.C:105-109
+      pecfac = 0.50 * (1.0 + tanh((pe - P.o.tanh_c1) / P.o.tanh_c2));
+    }
+    const double om_pecfac = 1.0 - pecfac;
+    double dqL = 0.0, dqR = 0.0, nonOrth = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double dxj = R.x[j] - L.x[j];
+      dqL += 0.5 * dxj * L.g[j];
+      dqR += 0.5 * dxj * R.g[j];
+      const double axj = av[j];
+      const double kxj = axj - asq * inv_axdx * dxj;
+      const double GjIp = 0.5 * (L.g[j] + R.g[j]);
+      nonOrth += -viscIp * kxj * GjIp;
+    }
+    double limitL = 1.0, limitR = 1.0;
+    const double dq = R.q - L.q;
+    if (P.o.use_limiter) {
+      const double dqMl = 2.0 * 2.0 * dqL - dq;
+      const double dqMr = 2.0 * 2.0 * dqR - dq;
+      limitL = van_leer(dqMl, dq, small);
+      limitR = van_leer(dqMr, dq, small);
+    }
+    const double qIpL = L.q + dqL * hoUpwind * limitL;
+    const double qIpR = R.q - dqR * hoUpwind * limitR;
+
+    const double lhsfac = -viscIp * asq * inv_axdx;
+    const double diffFlux = lhsfac * (R.q - L.q) + nonOrth;
+    lhs[0] = -lhsfac;
+    lhs[1] = +lhsfac;
+    rhs[0] = -diffFlux;
+    lhs[2] = +lhsfac;
+    lhs[3] = -lhsfac;
+    rhs[1] = diffFlux;
+
+    const double qIp = 0.5 * (L.q + R.q);
+    const double qUpwind = (tmdot > 0) ? alphaUpw * qIpL + om_alphaUpw * qIp
+                                       : alphaUpw * qIpR + om_alphaUpw * qIp;
+    const double qHatL = alpha * qIpL + om_alpha * qIp;
+    const double qHatR = alpha * qIpR + om_alpha * qIp;
+    const double qCds = 0.5 * (qHatL + qHatR);
+    const double aflux = tmdot * (pecfac * qUpwind + om_pecfac * qCds);
+
+    double alhsfac = 0.5 * (tmdot + fabs(tmdot)) * pecfac * alphaUpw + 0.5 * alpha * om_pecfac * tmdot;
+    lhs[0] += alhsfac;
+    lhs[2] -= alhsfac;
+    alhsfac = 0.5 * (tmdot - fabs(tmdot)) * pecfac * alphaUpw + 0.5 * alpha * om_pecfac * tmdot;
+    lhs[3] -= alhsfac;
+    lhs[1] += alhsfac;
+    alhsfac = 0.5 * tmdot * (pecfac * om_alphaUpw + om_pecfac * om_alpha);
+    lhs[0] += alhsfac;
+    lhs[1] += alhsfac;
+    lhs[2] -= alhsfac;
+    lhs[3] -= alhsfac;
+    rhs[0] -= aflux;
+    rhs[1] += aflux;
+  }
+};
+
+template <class Node>
+__device__ __forceinline__ Node select(bool c, const Node &a, const Node &b)
+{
+  return c ? a : b;
+}
+
+// --------------------------------------------------------------------------------------
+// Row-gather ("owner computes") assembly: one thread per matrix row walks the row's
+// entries, recomputes the flux of each incident edge and keeps only its own row's share.
+// Every matrix value and rhs entry has exactly one writer: deterministic, no atomics, no
+// colouring, and with SET (matrix logically zero) no read of the old values at all.
+// All accesses are lane-contiguous in the SELL layout; neighbour gathers are contiguous
+// too on lattice-ordered meshes.
+template <class Op, bool SET>
+__global__ __launch_bounds__(SELL_C) void k_assemble_rows(SellView A, typename Op::Params P,
+                                                           double *__restrict__ rhs)
+{
+  const int slice = xcd_slice(blockIdx.x, A.nSlices);
+  const int r = threadIdx.x;
+  const int row = slice * SELL_C + r;
+  if (row >= A.nRows) return;
+  const long long off = A.sliceOff[slice];
+  const int w = A.sliceWidth[slice];
+  const typename Op::Node own = Op::load(P, row);
+  double diag = 0.0, b = 0.0;
+  long long diagPos = -1;
+  for (int k = 0; k < w; ++k) {
+    const long long pos = off + (long long)k * SELL_C + r;
+    const unsigned tag = A.tags[pos];
+    if (tag >= TAG_OTHER) {
+      if (tag == TAG_DIAG) diagPos = pos;
+      else if (SET) A.vals[pos] = 0.0;
+      continue;
+    }
+    const int c = A.cols[pos];
+    const long long e = tag & 0x7FFFFFFFu;
+    const bool isR = (tag >> 31) != 0;
+    const typename Op::Node nb = Op::load(P, c);
+    double lhs[4], rh[2];
+    Op::edge(P, e, select(isR, nb, own), select(isR, own, nb), lhs, rh);
+    const double offd = isR ? lhs[2] : lhs[1];
+    diag += isR ? lhs[3] : lhs[0];
+    b += isR ? rh[1] : rh[0];
+    if (SET) A.vals[pos] = offd;
+    else A.vals[pos] += offd;
+  }
+  if (diagPos >= 0) {
+    if (SET) A.vals[diagPos] = diag;
+    else A.vals[diagPos] += diag;
+  }
+  if (SET) rhs[row] = b;
+  else rhs[row] += b;
+}
+
+__device__ __forceinline__ void add_plain(double *p, double v) { *p += v; }
+__device__ __forceinline__ void add_atomic(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+// Edge-parallel assembly (the reference's loop shape): one thread per edge, pre-computed
+// matrix slots.  The two off-diagonal slots of an edge have a single writer; diagonal and
+// rhs are shared between the edges of a node and need either colouring (COLORED: launched
+// once per colour, plain adds, deterministic) or fp64 atomics (ATOMIC).
+template <class Op, bool ATOMIC>
+__global__ __launch_bounds__(256) void k_assemble_edges(long long n, long long first,
+                                                         const int *__restrict__ perm,
+                                                         const int *__restrict__ eL,
+                                                         const int *__restrict__ eR,
+                                                         const int *__restrict__ slots,
+                                                         long long nEdges, typename Op::Params P,
+                                                         double *vals, double *rhs)
+{
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const long long e = perm ? perm[first + t] : first + t;
+  const int L = eL[e], R = eR[e];
+  const typename Op::Node nL = Op::load(P, L), nR = Op::load(P, R);
+  double lhs[4], rh[2];
+  Op::edge(P, e, nL, nR, lhs, rh);
+  const int sLL = slots[e], sLR = slots[nEdges + e], sRL = slots[2 * nEdges + e],
+            sRR = slots[3 * nEdges + e];
+  if (sLL >= 0) {
+    if (ATOMIC) { add_atomic(vals + sLL, lhs[0]); add_atomic(rhs + L, rh[0]); }
+    else { add_plain(vals + sLL, lhs[0]); add_plain(rhs + L, rh[0]); }
+    add_plain(vals + sLR, lhs[1]);
+  }
+  if (sRR >= 0) {
+    if (ATOMIC) { add_atomic(vals + sRR, lhs[3]); add_atomic(rhs + R, rh[1]); }
+    else { add_plain(vals + sRR, lhs[3]); add_plain(rhs + R, rh[1]); }
+    add_plain(vals + sRL, lhs[2]);
+  }
+}
+
+template <class Op>
+int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
+{
+  if (h->nEdges == 0 || h->nOwned == 0) return materialize_zero(h);
+  if (mode == NALU_GPU_SCATTER_ROWS) {
+    const bool set = h->lazyZero;
+    h->lazyZero = false;
+    timer_begin(h, NALU_GPU_T_ASSEMBLE_EDGES);
+    if (set) k_assemble_rows<Op, true><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), P, h->dRhs);
+    else k_assemble_rows<Op, false><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), P, h->dRhs);
+    timer_end(h, NALU_GPU_T_ASSEMBLE_EDGES);
+    NG_HIP(hipGetLastError());
+    return NALU_GPU_OK;
+  }
+  NG_TRY(materialize_zero(h));
+  NG_TRY(ensure_edge_slots(h));
+  if (mode == NALU_GPU_SCATTER_ATOMIC) {
+    timer_begin(h, NALU_GPU_T_ASSEMBLE_EDGES);
+    k_assemble_edges<Op, true><<<(unsigned)((h->nEdges + 255) / 256), 256, 0, h->stream>>>(
+        h->nEdges, 0, nullptr, h->dEdgeL, h->dEdgeR, h->dSlots, h->nEdges, P, h->dVals, h->dRhs);
+    timer_end(h, NALU_GPU_T_ASSEMBLE_EDGES);
+    NG_HIP(hipGetLastError());
+    return NALU_GPU_OK;
+  }
+  NG_REQUIRE(mode == NALU_GPU_SCATTER_COLORED, NALU_GPU_EINVAL, "unknown scatter mode %d", mode);
+  NG_TRY(ensure_colors(h));
+  timer_begin(h, NALU_GPU_T_ASSEMBLE_EDGES);
+  for (int c = 0; c < h->nColors; ++c) {
+    const long long n = h->colorOff[c + 1] - h->colorOff[c];
+    if (n == 0) continue;
+    k_assemble_edges<Op, false><<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(
+        n, h->colorOff[c], h->dColorPerm, h->dEdgeL, h->dEdgeR, h->dSlots, h->nEdges, P, h->dVals,
+        h->dRhs);
+  }
+  timer_end(h, NALU_GPU_T_ASSEMBLE_EDGES);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+bool vec3_ok(const nalu_gpu_vec3 &v) { return v.x && v.y && v.z; }
+
+// ------------------------------------------------------------------ mdot / gradient
+__global__ __launch_bounds__(256) void k_mdot(long long nEdges, const int *__restrict__ eL,
+                                               const int *__restrict__ eR, ContParams P,
+                                               double *__restrict__ mdot)
+{
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nEdges) return;
+  double lhsfac;
+  mdot[e] = ContOp::flux(P, e, ContOp::load(P, eL[e]), ContOp::load(P, eR[e]), lhsfac);
+}
+
+// src/AssembleNodalGradEdgeAlgorithm.C:87-114 as a row gather (same summation order as the
+// edge loop on (L,R)-sorted edges)
+__global__ __launch_bounds__(SELL_C) void k_nodal_grad(SellView A, nalu_gpu_vec3 area,
+                                                        const double *__restrict__ vol,
+                                                        const double *__restrict__ q,
+                                                        double *__restrict__ gx,
+                                                        double *__restrict__ gy,
+                                                        double *__restrict__ gz)
+{
+  const int slice = xcd_slice(blockIdx.x, A.nSlices);
+  const int r = threadIdx.x;
+  const int row = slice * SELL_C + r;
+  if (row >= A.nRows) return;
+  const long long off = A.sliceOff[slice];
+  const int w = A.sliceWidth[slice];
+  const double qi = q[row];
+  const double invVol = 1.0 / vol[row];
+  double g[3] = {0.0, 0.0, 0.0};
+  for (int k = 0; k < w; ++k) {
+    const long long pos = off + (long long)k * SELL_C + r;
+    const unsigned tag = A.tags[pos];
+    if (tag >= TAG_OTHER) continue;
+    const long long e = tag & 0x7FFFFFFFu;
+    const bool isR = (tag >> 31) != 0;
+    const double qn = q[A.cols[pos]];
+    const double qip = isR ? 0.5 * (qn + qi) : 0.5 * (qi + qn);
+    const double a[3] = {area.x[e], area.y[e], area.z[e]};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double ajQip = a[j] * qip;
+      if (isR) g[j] -= ajQip * invVol;
+      else g[j] += ajQip * invVol;
+    }
+  }
+  gx[row] = g[0];
+  gy[row] = g[1];
+  gz[row] = g[2];
+}
+
+// src/AssembleNodeSolverAlgorithm.C:84-110 + src/ScalarMassBackwardEulerNodeSuppAlg.C:72-79
+__global__ __launch_bounds__(SELL_C) void k_mass_be(SellView A, const double *__restrict__ qN,
+                                                     const double *__restrict__ qNp1,
+                                                     const double *__restrict__ rhoN,
+                                                     const double *__restrict__ rhoNp1,
+                                                     const double *__restrict__ vol, double dt,
+                                                     double *__restrict__ rhs)
+{
+  const int slice = blockIdx.x;
+  const int r = threadIdx.x;
+  const int row = slice * SELL_C + r;
+  if (row >= A.nRows) return;
+  const long long off = A.sliceOff[slice];
+  const int w = A.sliceWidth[slice];
+  const double lhsTime = rhoNp1[row] * vol[row] / dt;
+  const double res = (rhoNp1[row] * qNp1[row] - qN[row] * rhoN[row]) * vol[row] / dt;
+  for (int k = 0; k < w; ++k) {
+    const long long pos = off + (long long)k * SELL_C + r;
+    if (A.tags[pos] == TAG_DIAG) {
+      A.vals[pos] += lhsTime;
+      break;
+    }
+  }
+  rhs[row] += (0.0 - res);
+}
+
+}  // namespace
+
+#define NG_FINALIZED(h)                                         \
+  do {                                                          \
+    NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");              \
+    NG_REQUIRE((h)->state == 2, NALU_GPU_ESTATE,                \
+               "linear system is not finalized");               \
+    NG_HIP(hipSetDevice((h)->device));                          \
+  } while (0)
+
+extern "C" int nalu_gpu_assemble_continuity_edges(nalu_gpu_linsys *h,
+                                                  const nalu_gpu_continuity_fields *f, double dt,
+                                                  double gamma1, double noc_fac,
+                                                  double interp_together, int mode)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(f && vec3_ok(f->coordinates) && vec3_ok(f->dpdx) && vec3_ok(f->velocity) &&
+                 f->pressure && f->density && vec3_ok(f->edge_area),
+             NALU_GPU_EINVAL, "continuity fields: null device pointer");
+  NG_REQUIRE(gamma1 != 0.0 && dt != 0.0, NALU_GPU_EINVAL, "dt and gamma1 must be non-zero");
+  ContParams P;
+  P.f = *f;
+  P.tau = dt / gamma1;  // projTimeScale (:90)
+  P.noc = noc_fac;
+  P.interp = interp_together;
+  return assemble<ContOp>(h, P, mode);
+}
+
+extern "C" int nalu_gpu_assemble_scalar_edges(nalu_gpu_linsys *h, const nalu_gpu_scalar_fields *f,
+                                              const nalu_gpu_scalar_options *o, int mode)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(f && o && vec3_ok(f->coordinates) && vec3_ok(f->dqdx) && vec3_ok(f->velocity) &&
+                 f->scalar_q && f->density && f->diff_flux_coeff && vec3_ok(f->edge_area) &&
+                 f->mass_flow_rate,
+             NALU_GPU_EINVAL, "scalar fields: null device pointer");
+  NG_REQUIRE(o->peclet_kind == NALU_GPU_PECLET_CLASSIC || o->peclet_kind == NALU_GPU_PECLET_TANH,
+             NALU_GPU_EINVAL, "unknown peclet function %d", o->peclet_kind);
+  ScalParams P;
+  P.f = *f;
+  P.o = *o;
+  return assemble<ScalOp>(h, P, mode);
+}
+
+extern "C" int nalu_gpu_assemble_scalar_mass_be(nalu_gpu_linsys *h, const double *qN,
+                                                const double *qNp1, const double *rhoN,
+                                                const double *rhoNp1, const double *vol, double dt)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(qN && qNp1 && rhoN && rhoNp1 && vol && dt != 0.0, NALU_GPU_EINVAL, "bad mass-term input");
+  NG_TRY(materialize_zero(h));
+  if (h->nSlices)
+    k_mass_be<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), qN, qNp1, rhoN, rhoNp1, vol, dt, h->dRhs);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_compute_mdot_edges(nalu_gpu_linsys *h, const nalu_gpu_continuity_fields *f,
+                                           double dt, double gamma1, double noc_fac,
+                                           double interp_together, double *mdot_dev)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(f && mdot_dev && vec3_ok(f->coordinates) && vec3_ok(f->dpdx) && vec3_ok(f->velocity) &&
+                 f->pressure && f->density && vec3_ok(f->edge_area),
+             NALU_GPU_EINVAL, "mdot: null device pointer");
+  ContParams P;
+  P.f = *f;
+  P.tau = dt / gamma1;
+  P.noc = noc_fac;
+  P.interp = interp_together;
+  if (h->nEdges)
+    k_mdot<<<(unsigned)((h->nEdges + 255) / 256), 256, 0, h->stream>>>(h->nEdges, h->dEdgeL, h->dEdgeR, P, mdot_dev);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_nodal_grad_edges(nalu_gpu_linsys *h, nalu_gpu_vec3 area, const double *vol,
+                                         const double *q, double *gx, double *gy, double *gz)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(vec3_ok(area) && vol && q && gx && gy && gz, NALU_GPU_EINVAL, "nodal grad: null pointer");
+  if (h->nSlices)
+    k_nodal_grad<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), area, vol, q, gx, gy, gz);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}

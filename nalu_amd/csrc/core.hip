@@ -1,0 +1,936 @@
+// core.hip -- handle lifetime, graph construction, CSR/SELL set-up, zero / sumInto /
+// Dirichlet rows, halo plumbing and timers of libnalu_gpu.so (gfx950).
+#include <algorithm>
+#include <cstdarg>
+#include <cstring>
+#include <numeric>
+#include <thread>
+
+#include "internal.hpp"
+
+using namespace nalu_gpu;
+
+// ------------------------------------------------------------------------- errors
+static thread_local std::string g_err;
+
+int nalu_gpu::set_error(int code, const char *fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+extern "C" const char *nalu_gpu_last_error(void) { return g_err.c_str(); }
+extern "C" int nalu_gpu_version(void) { return 100; }
+
+// ------------------------------------------------------------------------- timers
+static hipEvent_t get_event(nalu_gpu_linsys *h)
+{
+  if (!h->eventPool.empty()) {
+    hipEvent_t e = h->eventPool.back();
+    h->eventPool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void nalu_gpu::timer_begin(nalu_gpu_linsys *h, int which)
+{
+  if (!h->profiling) return;
+  EventPair p;
+  p.a = get_event(h);
+  p.b = get_event(h);
+  (void)hipEventRecord(p.a, h->stream);
+  h->timers[which].pending.push_back(p);
+}
+
+void nalu_gpu::timer_end(nalu_gpu_linsys *h, int which)
+{
+  if (!h->profiling) return;
+  (void)hipEventRecord(h->timers[which].pending.back().b, h->stream);
+}
+
+static void drain_timers(nalu_gpu_linsys *h)
+{
+  for (int t = 0; t < NALU_GPU_T_COUNT; ++t) {
+    Timer &tm = h->timers[t];
+    for (EventPair &p : tm.pending) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        tm.totalMs += ms;
+        tm.count += 1;
+      }
+      h->eventPool.push_back(p.a);
+      h->eventPool.push_back(p.b);
+    }
+    tm.pending.clear();
+  }
+}
+
+extern "C" int nalu_gpu_set_profiling(nalu_gpu_linsys *h, int enabled)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  h->profiling = enabled != 0;
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_synchronize(nalu_gpu_linsys *h)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  NG_HIP(hipSetDevice(h->device));
+  NG_HIP(hipStreamSynchronize(h->stream));
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_get_timer(nalu_gpu_linsys *h, int which, double *total_ms, int64_t *count)
+{
+  NG_REQUIRE(h && which >= 0 && which < NALU_GPU_T_COUNT, NALU_GPU_EINVAL, "bad timer id");
+  NG_TRY(nalu_gpu_synchronize(h));
+  drain_timers(h);
+  if (total_ms) *total_ms = h->timers[which].totalMs;
+  if (count) *count = h->timers[which].count;
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_reset_timers(nalu_gpu_linsys *h)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  NG_TRY(nalu_gpu_synchronize(h));
+  drain_timers(h);
+  for (int t = 0; t < NALU_GPU_T_COUNT; ++t) {
+    h->timers[t].totalMs = 0.0;
+    h->timers[t].count = 0;
+  }
+  return NALU_GPU_OK;
+}
+
+// ----------------------------------------------------------------------- lifetime
+extern "C" int nalu_gpu_create(nalu_gpu_linsys **out, int device, int num_dof, void *hip_stream)
+{
+  NG_REQUIRE(out, NALU_GPU_EINVAL, "out is null");
+  NG_REQUIRE(num_dof == 1, NALU_GPU_EUNSUPPORTED,
+             "numDof = %d: only the numDof = 1 systems (continuity, scalar transport) are "
+             "supported", num_dof);
+  int ndev = 0;
+  NG_HIP(hipGetDeviceCount(&ndev));
+  NG_REQUIRE(device >= 0 && device < ndev, NALU_GPU_EINVAL, "device %d of %d", device, ndev);
+  NG_HIP(hipSetDevice(device));
+  nalu_gpu_linsys *h = new nalu_gpu_linsys();
+  h->device = device;
+  h->numDof = num_dof;
+  h->stream = (hipStream_t)hip_stream;  // NULL = the device's default stream
+  *out = h;
+  return NALU_GPU_OK;
+}
+
+#define NG_FREE(p)            \
+  do {                        \
+    if (p) (void)hipFree(p);  \
+    p = nullptr;              \
+  } while (0)
+
+extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
+{
+  if (!h) return NALU_GPU_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  drain_timers(h);
+  for (hipEvent_t e : h->eventPool) (void)hipEventDestroy(e);
+  NG_FREE(h->dSliceOff); NG_FREE(h->dSliceWidth); NG_FREE(h->dCols); NG_FREE(h->dVals);
+  NG_FREE(h->dTags); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
+  NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
+  NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
+  NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dReduce); NG_FREE(h->dScal);
+  NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
+  NG_FREE(h->dY); NG_FREE(h->dList); NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf);
+  NG_FREE(h->dRecvBuf);
+  if (h->hPinned) (void)hipHostFree(h->hPinned);
+  if (h->ownStream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return NALU_GPU_OK;
+}
+
+// -------------------------------------------------------------- graph construction
+extern "C" int nalu_gpu_begin_construction(nalu_gpu_linsys *h, int n_owned, int n_shared,
+                                           int n_ghost, const int64_t *gids,
+                                           const int *owner_ranks, int my_rank)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  // src/TpetraLinearSystem.C:165: a second begin while under construction is a no-op
+  if (h->state == 1) return NALU_GPU_OK;
+  NG_REQUIRE(h->state == 0, NALU_GPU_ESTATE,
+             "linear system already finalized (the reference deletes and recreates it, "
+             "src/LowMachEquationSystem.C:2947-2971)");
+  NG_REQUIRE(n_owned >= 0 && n_shared >= 0 && n_ghost >= 0 && gids, NALU_GPU_EINVAL,
+             "bad node counts");
+  const int64_t n = (int64_t)n_owned + n_shared + n_ghost;
+  NG_REQUIRE(n < (int64_t)TAG_MAX_EDGE, NALU_GPU_EINVAL, "too many local nodes");
+  // ordering rules of src/TpetraLinearSystem.C:247-285 and :1046-1074
+  for (int64_t i = 1; i < n_owned; ++i)
+    NG_REQUIRE(gids[i - 1] < gids[i], NALU_GPU_EINVAL,
+               "owned nodes must be sorted by global id (local %lld)", (long long)i);
+  for (int64_t i = n_owned + 1; i < n_owned + n_shared; ++i)
+    NG_REQUIRE(gids[i - 1] < gids[i], NALU_GPU_EINVAL,
+               "shared-not-owned nodes must be sorted by global id (local %lld)", (long long)i);
+  if (owner_ranks) {
+    for (int64_t i = 0; i < n_owned; ++i)
+      NG_REQUIRE(owner_ranks[i] == my_rank, NALU_GPU_EINVAL, "owned node %lld has owner %d",
+                 (long long)i, owner_ranks[i]);
+    for (int64_t i = n_owned; i < n; ++i)
+      NG_REQUIRE(owner_ranks[i] != my_rank, NALU_GPU_EINVAL,
+                 "non-owned node %lld is owned by this rank", (long long)i);
+    for (int64_t i = n_owned + n_shared + 1; i < n; ++i)
+      NG_REQUIRE(owner_ranks[i - 1] < owner_ranks[i] ||
+                     (owner_ranks[i - 1] == owner_ranks[i] && gids[i - 1] < gids[i]),
+                 NALU_GPU_EINVAL, "ghost nodes must be ordered by (owner, global id)");
+  }
+  h->nOwned = n_owned;
+  h->nShared = n_shared;
+  h->nGhost = n_ghost;
+  h->nCols = (int)n;
+  h->myRank = my_rank;
+  h->gids.assign(gids, gids + n);
+  if (owner_ranks) h->owners.assign(owner_ranks, owner_ranks + n);
+  else h->owners.assign((size_t)n, my_rank);
+  h->state = 1;
+  return NALU_GPU_OK;
+}
+
+static int add_block(nalu_gpu_linsys *h, int64_t n_ent, int npe, const int *nodes, bool isEdge)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  NG_REQUIRE(h->state == 1, NALU_GPU_ESTATE, "graph builders need begin_construction first");
+  NG_REQUIRE(n_ent >= 0 && npe >= 1 && (nodes || n_ent == 0), NALU_GPU_EINVAL, "bad entity list");
+  const int64_t tot = n_ent * npe;
+  for (int64_t i = 0; i < tot; ++i)
+    NG_REQUIRE(nodes[i] >= 0 && nodes[i] < h->nCols, NALU_GPU_EINVAL,
+               "entity %lld references local node %d outside [0,%d)", (long long)(i / npe),
+               nodes[i], h->nCols);
+  if (isEdge) {
+    NG_REQUIRE(h->nEdges + n_ent < (int64_t)TAG_MAX_EDGE, NALU_GPU_EINVAL, "too many edges");
+    for (int64_t e = 0; e < n_ent; ++e)
+      NG_REQUIRE(nodes[2 * e] != nodes[2 * e + 1], NALU_GPU_EINVAL, "degenerate edge %lld",
+                 (long long)e);
+    h->nEdges += n_ent;
+  }
+  EntBlock b;
+  b.npe = npe;
+  b.isEdge = isEdge;
+  b.nodes.assign(nodes, nodes + tot);
+  h->blocks.push_back(std::move(b));
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_build_node_graph(nalu_gpu_linsys *h, int64_t n, const int *lids)
+{
+  return add_block(h, n, 1, lids, false);
+}
+extern "C" int nalu_gpu_build_edge_to_node_graph(nalu_gpu_linsys *h, int64_t n_edges,
+                                                 const int *edge_nodes)
+{
+  return add_block(h, n_edges, 2, edge_nodes, true);
+}
+extern "C" int nalu_gpu_build_elem_to_node_graph(nalu_gpu_linsys *h, int64_t n_elems, int npe,
+                                                 const int *elem_nodes)
+{
+  return add_block(h, n_elems, npe, elem_nodes, false);
+}
+extern "C" int nalu_gpu_build_dirichlet_node_graph(nalu_gpu_linsys *h, int64_t, const int *)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  return NALU_GPU_OK;  // include/LinearSystem.h:68-75: default no-op
+}
+
+template <typename F>
+static void parallel_for(int64_t n, F f)
+{
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = std::max(1u, std::min(nt, 16u));
+  if (n < 200000) nt = 1;
+  if (nt == 1) {
+    f(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const int64_t a = t * chunk, b = std::min(n, a + chunk);
+    if (a >= b) break;
+    th.emplace_back([=]() { f(a, b); });
+  }
+  for (auto &t : th) t.join();
+}
+
+// CSR (host) -> SELL-C (device): one thread per row
+__global__ void k_csr_to_sell(int nRows, const long long *rowPtr, const int *colIdx,
+                              const long long *sliceOff, const int *sliceWidth, int *cols,
+                              unsigned *tags)
+{
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  const int slice = row / SELL_C, r = row % SELL_C;
+  const long long off = sliceOff[slice];
+  const int w = sliceWidth[slice];
+  if (row < nRows) {
+    const long long b = rowPtr[row];
+    const int len = (int)(rowPtr[row + 1] - b);
+    for (int k = 0; k < w; ++k) {
+      const long long pos = off + (long long)k * SELL_C + r;
+      if (k < len) {
+        const int c = colIdx[b + k];
+        cols[pos] = c;
+        tags[pos] = (c == row) ? TAG_DIAG : TAG_OTHER;
+      } else {
+        cols[pos] = row;
+        tags[pos] = TAG_PAD;
+      }
+    }
+  } else {  // rows beyond nRows in the last slice
+    for (int k = 0; k < w; ++k) {
+      const long long pos = off + (long long)k * SELL_C + r;
+      cols[pos] = 0;
+      tags[pos] = TAG_PAD;
+    }
+  }
+}
+
+__device__ __forceinline__ long long find_in_row(const long long *sliceOff, const int *sliceWidth,
+                                                 const int *cols, int row, int col)
+{
+  const int slice = row / SELL_C, r = row % SELL_C;
+  const long long off = sliceOff[slice];
+  const int w = sliceWidth[slice];
+  for (int k = 0; k < w; ++k) {
+    const long long pos = off + (long long)k * SELL_C + r;
+    if (cols[pos] == col) return pos;
+  }
+  return -1;
+}
+
+// tag the two off-diagonal entries of every edge
+__global__ void k_tag_edges(long long nEdges, const int *eL, const int *eR, int nOwned,
+                            const long long *sliceOff, const int *sliceWidth, const int *cols,
+                            unsigned *tags, int *err)
+{
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nEdges) return;
+  const int L = eL[e], R = eR[e];
+  if (L < nOwned) {
+    const long long pos = find_in_row(sliceOff, sliceWidth, cols, L, R);
+    if (pos < 0) atomicAdd(err, 1);
+    else {
+      if (tags[pos] != TAG_OTHER) atomicAdd(err + 1, 1);  // duplicate edge
+      tags[pos] = (unsigned)e;
+    }
+  }
+  if (R < nOwned) {
+    const long long pos = find_in_row(sliceOff, sliceWidth, cols, R, L);
+    if (pos < 0) atomicAdd(err, 1);
+    else {
+      if (tags[pos] != TAG_OTHER) atomicAdd(err + 1, 1);
+      tags[pos] = (unsigned)e | 0x80000000u;
+    }
+  }
+}
+
+extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  NG_REQUIRE(h->state == 1, NALU_GPU_ESTATE, "finalize needs a system under construction");
+  NG_HIP(hipSetDevice(h->device));
+  const int nO = h->nOwned;
+
+  // addConnections + insert_graph_connections (src/TpetraLinearSystem.C:355-371,877-917):
+  // the pattern of owned row a is {a} U {b : a and b share an entity}, columns ascending
+  // (LocalGraphArrays::insertIndices, include/LinearSolver.h:81-93).
+  std::vector<int64_t> cnt((size_t)nO + 1, 0);
+  for (const EntBlock &b : h->blocks) {
+    const int64_t ne = (int64_t)b.nodes.size() / b.npe;
+    for (int64_t e = 0; e < ne; ++e)
+      for (int i = 0; i < b.npe; ++i) {
+        const int a = b.nodes[e * b.npe + i];
+        if (a < nO) cnt[a + 1] += b.npe - 1;
+      }
+  }
+  for (int i = 0; i < nO; ++i) cnt[i + 1] += cnt[i] + 1;  // +1: the diagonal
+  // (cnt[i] is now the start of row i's scratch list)
+  std::vector<int> scratch((size_t)cnt[nO]);
+  std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+  for (int i = 0; i < nO; ++i) scratch[fill[i]++] = i;
+  for (const EntBlock &b : h->blocks) {
+    const int64_t ne = (int64_t)b.nodes.size() / b.npe;
+    for (int64_t e = 0; e < ne; ++e) {
+      const int *en = &b.nodes[e * b.npe];
+      for (int i = 0; i < b.npe; ++i) {
+        const int a = en[i];
+        if (a >= nO) continue;
+        for (int j = 0; j < b.npe; ++j)
+          if (j != i) scratch[fill[a]++] = en[j];
+      }
+    }
+  }
+  std::vector<int> len((size_t)nO);
+  parallel_for(nO, [&](int64_t r0, int64_t r1) {
+    for (int64_t i = r0; i < r1; ++i) {
+      int *b = &scratch[cnt[i]], *e = &scratch[cnt[i + 1]];
+      std::sort(b, e);
+      len[i] = (int)(std::unique(b, e) - b);
+    }
+  });
+  h->rowPtr.assign((size_t)nO + 1, 0);
+  for (int i = 0; i < nO; ++i) h->rowPtr[i + 1] = h->rowPtr[i] + len[i];
+  h->nnz = h->rowPtr[nO];
+  h->colIdx.resize((size_t)h->nnz);
+  parallel_for(nO, [&](int64_t r0, int64_t r1) {
+    for (int64_t i = r0; i < r1; ++i)
+      std::copy(&scratch[cnt[i]], &scratch[cnt[i]] + len[i], &h->colIdx[h->rowPtr[i]]);
+  });
+  std::vector<int>().swap(scratch);
+
+  // SELL slices
+  h->nSlices = (nO + SELL_C - 1) / SELL_C;
+  h->hSliceOff.assign((size_t)h->nSlices + 1, 0);
+  h->hSliceWidth.assign((size_t)std::max(h->nSlices, 1), 0);
+  for (int s = 0; s < h->nSlices; ++s) {
+    int w = 0;
+    const int r1 = std::min(nO, (s + 1) * SELL_C);
+    for (int r = s * SELL_C; r < r1; ++r) w = std::max(w, len[r]);
+    h->hSliceWidth[s] = w;
+    h->hSliceOff[s + 1] = h->hSliceOff[s] + (long long)w * SELL_C;
+  }
+  h->sellSize = h->hSliceOff[h->nSlices];
+
+  const size_t nS = (size_t)std::max(h->nSlices, 1), sz = (size_t)std::max<long long>(h->sellSize, 1);
+  NG_HIP(hipMalloc(&h->dSliceOff, sizeof(long long) * (nS + 1)));
+  NG_HIP(hipMalloc(&h->dSliceWidth, sizeof(int) * nS));
+  NG_HIP(hipMalloc(&h->dCols, sizeof(int) * sz));
+  NG_HIP(hipMalloc(&h->dTags, sizeof(unsigned) * sz));
+  NG_HIP(hipMalloc(&h->dVals, sizeof(double) * sz));
+  NG_HIP(hipMemcpyAsync(h->dSliceOff, h->hSliceOff.data(), sizeof(long long) * (h->nSlices + 1),
+                        hipMemcpyHostToDevice, h->stream));
+  NG_HIP(hipMemcpyAsync(h->dSliceWidth, h->hSliceWidth.data(), sizeof(int) * nS,
+                        hipMemcpyHostToDevice, h->stream));
+  NG_HIP(hipMemsetAsync(h->dVals, 0, sizeof(double) * sz, h->stream));
+  {
+    long long *dRowPtr = nullptr;
+    int *dColIdx = nullptr;
+    NG_HIP(hipMalloc(&dRowPtr, sizeof(long long) * ((size_t)nO + 1)));
+    NG_HIP(hipMalloc(&dColIdx, sizeof(int) * (size_t)std::max<int64_t>(h->nnz, 1)));
+    NG_HIP(hipMemcpyAsync(dRowPtr, h->rowPtr.data(), sizeof(long long) * ((size_t)nO + 1),
+                          hipMemcpyHostToDevice, h->stream));
+    NG_HIP(hipMemcpyAsync(dColIdx, h->colIdx.data(), sizeof(int) * (size_t)h->nnz,
+                          hipMemcpyHostToDevice, h->stream));
+    if (h->nSlices > 0)
+      k_csr_to_sell<<<h->nSlices, SELL_C, 0, h->stream>>>(nO, dRowPtr, dColIdx, h->dSliceOff,
+                                                           h->dSliceWidth, h->dCols, h->dTags);
+    NG_HIP(hipGetLastError());
+    NG_HIP(hipStreamSynchronize(h->stream));
+    (void)hipFree(dRowPtr);
+    (void)hipFree(dColIdx);
+  }
+
+  // edges: SoA copy on the device + per-entry edge tags
+  if (h->nEdges > 0) {
+    std::vector<int> eL((size_t)h->nEdges), eR((size_t)h->nEdges);
+    int64_t e0 = 0;
+    for (const EntBlock &b : h->blocks) {
+      if (!b.isEdge) continue;
+      const int64_t ne = (int64_t)b.nodes.size() / 2;
+      for (int64_t e = 0; e < ne; ++e) {
+        eL[e0 + e] = b.nodes[2 * e];
+        eR[e0 + e] = b.nodes[2 * e + 1];
+      }
+      e0 += ne;
+    }
+    NG_HIP(hipMalloc(&h->dEdgeL, sizeof(int) * (size_t)h->nEdges));
+    NG_HIP(hipMalloc(&h->dEdgeR, sizeof(int) * (size_t)h->nEdges));
+    NG_HIP(hipMemcpy(h->dEdgeL, eL.data(), sizeof(int) * (size_t)h->nEdges, hipMemcpyHostToDevice));
+    NG_HIP(hipMemcpy(h->dEdgeR, eR.data(), sizeof(int) * (size_t)h->nEdges, hipMemcpyHostToDevice));
+    int *dErr = nullptr;
+    NG_HIP(hipMalloc(&dErr, 2 * sizeof(int)));
+    NG_HIP(hipMemsetAsync(dErr, 0, 2 * sizeof(int), h->stream));
+    const long long nb = (h->nEdges + 255) / 256;
+    k_tag_edges<<<(unsigned)nb, 256, 0, h->stream>>>(h->nEdges, h->dEdgeL, h->dEdgeR, nO,
+                                                      h->dSliceOff, h->dSliceWidth, h->dCols,
+                                                      h->dTags, dErr);
+    NG_HIP(hipGetLastError());
+    int err[2] = {0, 0};
+    NG_HIP(hipMemcpy(err, dErr, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(dErr);
+    NG_REQUIRE(err[0] == 0, NALU_GPU_EINVAL, "internal: %d edge entries missing from the graph", err[0]);
+    NG_REQUIRE(err[1] == 0, NALU_GPU_EINVAL, "%d duplicate edges (same node pair twice)", err[1]);
+  }
+  // entity lists are no longer needed
+  std::vector<EntBlock>().swap(h->blocks);
+
+  // vectors + solver workspace that does not depend on the solver configuration
+  const size_t nC = (size_t)std::max(h->nCols, 1), nR = (size_t)std::max(nO, 1);
+  NG_HIP(hipMalloc(&h->dRhs, sizeof(double) * nR));
+  NG_HIP(hipMalloc(&h->dX, sizeof(double) * nC));
+  NG_HIP(hipMalloc(&h->dDinv, sizeof(double) * nC));
+  NG_HIP(hipMalloc(&h->dR, sizeof(double) * nR));
+  NG_HIP(hipMalloc(&h->dP, sizeof(double) * nC));
+  NG_HIP(hipMalloc(&h->dQ, sizeof(double) * nR));
+  NG_HIP(hipMalloc(&h->dW, sizeof(double) * nC));
+  NG_HIP(hipMalloc(&h->dT, sizeof(double) * nC));
+  NG_HIP(hipMalloc(&h->dPartials, sizeof(double) * PARTIAL_SLOTS * MAX_BLOCKS));
+  NG_HIP(hipMalloc(&h->dReduce, sizeof(double) * REDUCE_CAP));
+  NG_HIP(hipMalloc(&h->dScal, sizeof(SolverScalars)));
+  NG_HIP(hipHostMalloc(&h->hPinned, 4096, hipHostMallocDefault));
+  NG_HIP(hipMemsetAsync(h->dRhs, 0, sizeof(double) * nR, h->stream));
+  NG_HIP(hipMemsetAsync(h->dX, 0, sizeof(double) * nC, h->stream));
+  NG_HIP(hipMemsetAsync(h->dP, 0, sizeof(double) * nC, h->stream));
+  NG_HIP(hipMemsetAsync(h->dW, 0, sizeof(double) * nC, h->stream));
+  NG_HIP(hipMemsetAsync(h->dT, 0, sizeof(double) * nC, h->stream));
+  NG_HIP(hipMemsetAsync(h->dDinv, 0, sizeof(double) * nC, h->stream));
+  NG_HIP(hipMemsetAsync(h->dReduce, 0, sizeof(double) * REDUCE_CAP, h->stream));
+  NG_HIP(hipStreamSynchronize(h->stream));
+  h->state = 2;
+  return NALU_GPU_OK;
+}
+
+// --------------------------------------------------------------------------- views
+#define NG_FINALIZED(h)                                         \
+  do {                                                          \
+    NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");              \
+    NG_REQUIRE((h)->state == 2, NALU_GPU_ESTATE,                \
+               "linear system is not finalized");               \
+    NG_HIP(hipSetDevice((h)->device));                          \
+  } while (0)
+
+extern "C" int nalu_gpu_get_sizes(nalu_gpu_linsys *h, int64_t *n_rows, int64_t *n_cols, int64_t *nnz)
+{
+  NG_FINALIZED(h);
+  if (n_rows) *n_rows = h->nOwned;
+  if (n_cols) *n_cols = h->nCols;
+  if (nnz) *nnz = h->nnz;
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_get_graph(nalu_gpu_linsys *h, int64_t *row_ptr, int *col_idx)
+{
+  NG_FINALIZED(h);
+  if (row_ptr) std::copy(h->rowPtr.begin(), h->rowPtr.end(), row_ptr);
+  if (col_idx) std::copy(h->colIdx.begin(), h->colIdx.end(), col_idx);
+  return NALU_GPU_OK;
+}
+
+// gather / scatter between the CSR value order and the SELL layout
+template <bool TO_CSR>
+__global__ void k_sell_csr_values(int nRows, const long long *rowPtr, const long long *sliceOff,
+                                  double *sellVals, double *csrVals)
+{
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nRows) return;
+  const long long off = sliceOff[row / SELL_C];
+  const int r = row % SELL_C;
+  const long long b = rowPtr[row];
+  const int len = (int)(rowPtr[row + 1] - b);
+  for (int k = 0; k < len; ++k) {
+    const long long pos = off + (long long)k * SELL_C + r;
+    if (TO_CSR) csrVals[b + k] = sellVals[pos];
+    else sellVals[pos] = csrVals[b + k];
+  }
+}
+
+static int csr_values_io(nalu_gpu_linsys *h, double *host, bool toHost)
+{
+  NG_TRY(materialize_zero(h));
+  long long *dRowPtr = nullptr;
+  double *dCsr = nullptr;
+  const size_t nnz = (size_t)std::max<int64_t>(h->nnz, 1);
+  NG_HIP(hipMalloc(&dRowPtr, sizeof(long long) * ((size_t)h->nOwned + 1)));
+  NG_HIP(hipMalloc(&dCsr, sizeof(double) * nnz));
+  NG_HIP(hipMemcpyAsync(dRowPtr, h->rowPtr.data(), sizeof(long long) * ((size_t)h->nOwned + 1),
+                        hipMemcpyHostToDevice, h->stream));
+  const int nb = (h->nOwned + 255) / 256;
+  if (toHost) {
+    if (nb) k_sell_csr_values<true><<<nb, 256, 0, h->stream>>>(h->nOwned, dRowPtr, h->dSliceOff, h->dVals, dCsr);
+    NG_HIP(hipGetLastError());
+    NG_HIP(hipStreamSynchronize(h->stream));
+    NG_HIP(hipMemcpy(host, dCsr, sizeof(double) * (size_t)h->nnz, hipMemcpyDeviceToHost));
+  } else {
+    NG_HIP(hipMemcpyAsync(dCsr, host, sizeof(double) * (size_t)h->nnz, hipMemcpyHostToDevice, h->stream));
+    if (nb) k_sell_csr_values<false><<<nb, 256, 0, h->stream>>>(h->nOwned, dRowPtr, h->dSliceOff, h->dVals, dCsr);
+    NG_HIP(hipGetLastError());
+    NG_HIP(hipStreamSynchronize(h->stream));
+  }
+  (void)hipFree(dRowPtr);
+  (void)hipFree(dCsr);
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_get_matrix_values(nalu_gpu_linsys *h, double *values)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(values, NALU_GPU_EINVAL, "values is null");
+  return csr_values_io(h, values, true);
+}
+
+extern "C" int nalu_gpu_set_matrix_values(nalu_gpu_linsys *h, const double *values)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(values, NALU_GPU_EINVAL, "values is null");
+  return csr_values_io(h, const_cast<double *>(values), false);
+}
+
+extern "C" int nalu_gpu_get_rhs(nalu_gpu_linsys *h, double *rhs)
+{
+  NG_FINALIZED(h);
+  NG_TRY(materialize_zero(h));
+  NG_HIP(hipStreamSynchronize(h->stream));
+  NG_HIP(hipMemcpy(rhs, h->dRhs, sizeof(double) * (size_t)h->nOwned, hipMemcpyDeviceToHost));
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_set_rhs(nalu_gpu_linsys *h, const double *rhs)
+{
+  NG_FINALIZED(h);
+  NG_TRY(materialize_zero(h));
+  NG_HIP(hipStreamSynchronize(h->stream));
+  NG_HIP(hipMemcpy(h->dRhs, rhs, sizeof(double) * (size_t)h->nOwned, hipMemcpyHostToDevice));
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_get_solution(nalu_gpu_linsys *h, double *x)
+{
+  NG_FINALIZED(h);
+  NG_HIP(hipStreamSynchronize(h->stream));
+  NG_HIP(hipMemcpy(x, h->dX, sizeof(double) * (size_t)h->nOwned, hipMemcpyDeviceToHost));
+  return NALU_GPU_OK;
+}
+
+// ------------------------------------------------------------- zero / sumInto / BC
+// zeroSystem is lazy: it only marks matrix and rhs as logically zero.  The first bulk
+// row-gather assembly then *stores* its rows (no memset, no read-modify-write); any other
+// consumer materialises the zeros first.
+extern "C" int nalu_gpu_zero_system(nalu_gpu_linsys *h)
+{
+  NG_FINALIZED(h);
+  h->lazyZero = true;
+  // sln_->putScalar(0) (src/TpetraLinearSystem.C:1347): the solve starts from x0 = 0 itself
+  return NALU_GPU_OK;
+}
+
+int nalu_gpu::materialize_zero(nalu_gpu_linsys *h)
+{
+  if (!h->lazyZero) return NALU_GPU_OK;
+  timer_begin(h, NALU_GPU_T_ZERO);
+  NG_HIP(hipMemsetAsync(h->dVals, 0, sizeof(double) * (size_t)std::max<long long>(h->sellSize, 1), h->stream));
+  NG_HIP(hipMemsetAsync(h->dRhs, 0, sizeof(double) * (size_t)std::max(h->nOwned, 1), h->stream));
+  timer_end(h, NALU_GPU_T_ZERO);
+  h->lazyZero = false;
+  return NALU_GPU_OK;
+}
+
+struct SumIntoArgs {
+  int nPos, nRhs;
+  long long pos[64];
+  double val[64];
+  int row[8];
+  double rhs[8];
+};
+
+__global__ void k_sum_into(SumIntoArgs a, double *vals, double *rhs)
+{
+  const int t = threadIdx.x;
+  if (t < a.nPos) vals[a.pos[t]] += a.val[t];
+  if (t < a.nRhs) rhs[a.row[t]] += a.rhs[t];
+}
+
+extern "C" int nalu_gpu_sum_into(nalu_gpu_linsys *h, int n_obj, const int *node_lids,
+                                 const double *rhs, const double *lhs)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(n_obj >= 1 && n_obj <= 8 && node_lids && rhs && lhs, NALU_GPU_EINVAL,
+             "sum_into supports 1..8 entities per call (got %d)", n_obj);
+  for (int i = 0; i < n_obj; ++i)
+    NG_REQUIRE(node_lids[i] >= 0 && node_lids[i] < h->nCols, NALU_GPU_EINVAL,
+               "local node %d outside [0,%d)", node_lids[i], h->nCols);
+  NG_TRY(materialize_zero(h));
+  // src/TpetraLinearSystem.C:1486-1506: rows beyond maxOwnedRowId_ go to the shared-not-
+  // owned matrix there; here those rows are assembled by their owner, so they are skipped.
+  // Columns missing from the row are skipped silently (:1370-1382).
+  SumIntoArgs a;
+  a.nPos = a.nRhs = 0;
+  for (int i = 0; i < n_obj; ++i) {
+    const int row = node_lids[i];
+    if (row >= h->nOwned) continue;
+    const int64_t b = h->rowPtr[row], e = h->rowPtr[row + 1];
+    const long long off = h->hSliceOff[row / SELL_C];
+    for (int j = 0; j < n_obj; ++j) {
+      const int *it = std::lower_bound(&h->colIdx[b], &h->colIdx[b] + (e - b), node_lids[j]);
+      if (it == &h->colIdx[b] + (e - b) || *it != node_lids[j]) continue;
+      const int k = (int)(it - &h->colIdx[b]);
+      // duplicate entities in one call accumulate, as the sorted scan would
+      a.pos[a.nPos] = off + (long long)k * SELL_C + row % SELL_C;
+      a.val[a.nPos] = lhs[i * n_obj + j];
+      ++a.nPos;
+    }
+    a.row[a.nRhs] = row;
+    a.rhs[a.nRhs] = rhs[i];
+    ++a.nRhs;
+  }
+  // one thread per entry; duplicate positions (same node twice) need serial adds
+  bool dup = false;
+  for (int i = 0; i < a.nPos && !dup; ++i)
+    for (int j = i + 1; j < a.nPos; ++j)
+      if (a.pos[i] == a.pos[j]) { dup = true; break; }
+  NG_REQUIRE(!dup, NALU_GPU_EINVAL, "sum_into: the same node appears twice in one call");
+  if (a.nPos || a.nRhs) k_sum_into<<<1, 64, 0, h->stream>>>(a, h->dVals, h->dRhs);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+int nalu_gpu::ensure_list(nalu_gpu_linsys *h, int64_t n, const int *lids)
+{
+  if (n > h->listCap) {
+    // the stream may still read the old list
+    NG_HIP(hipStreamSynchronize(h->stream));
+    if (h->dList) (void)hipFree(h->dList);
+    h->listCap = std::max<int64_t>(n, 1024);
+    NG_HIP(hipMalloc(&h->dList, sizeof(int) * (size_t)h->listCap));
+  }
+  // pageable source: hipMemcpyAsync stages it before returning
+  NG_HIP(hipMemcpyAsync(h->dList, lids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  NG_HIP(hipStreamSynchronize(h->stream));
+  return NALU_GPU_OK;
+}
+
+// applyDirichletBCs / resetRows (src/TpetraLinearSystem.C:1546-1583, 1650-1683)
+__global__ void k_replace_rows(SellView A, int n, const int *lids, double diagVal,
+                               const double *solution, const double *bc, double *rhs)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int row = lids[t];
+  if (row >= A.nRows) return;  // shared copy: its row lives (and is replaced) on the owner
+  const int slice = row / SELL_C, r = row % SELL_C;
+  const long long off = A.sliceOff[slice];
+  const int w = A.sliceWidth[slice];
+  for (int k = 0; k < w; ++k) {
+    const long long pos = off + (long long)k * SELL_C + r;
+    A.vals[pos] = (A.tags[pos] == TAG_DIAG) ? diagVal : 0.0;
+  }
+  rhs[row] = bc ? (bc[row] - solution[row]) : 0.0;
+}
+
+static int replace_rows(nalu_gpu_linsys *h, int64_t n, const int *lids, double diagVal,
+                        const double *sol, const double *bc)
+{
+  NG_REQUIRE(n >= 0 && (lids || n == 0), NALU_GPU_EINVAL, "bad node list");
+  for (int64_t i = 0; i < n; ++i)
+    NG_REQUIRE(lids[i] >= 0 && lids[i] < h->nOwned + h->nShared, NALU_GPU_EINVAL,
+               "node %d is neither owned nor shared (src/TpetraLinearSystem.C:1558-1561)", lids[i]);
+  NG_TRY(materialize_zero(h));
+  if (n == 0) return NALU_GPU_OK;
+  NG_TRY(ensure_list(h, n, lids));
+  timer_begin(h, NALU_GPU_T_BC);
+  k_replace_rows<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(sell_view(h), (int)n, h->dList,
+                                                                     diagVal, sol, bc, h->dRhs);
+  timer_end(h, NALU_GPU_T_BC);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_apply_dirichlet(nalu_gpu_linsys *h, int64_t n, const int *lids,
+                                        const double *solution_dev, const double *bc_dev)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(solution_dev && bc_dev, NALU_GPU_EINVAL, "null field");
+  return replace_rows(h, n, lids, 1.0, solution_dev, bc_dev);
+}
+
+extern "C" int nalu_gpu_reset_rows(nalu_gpu_linsys *h, int64_t n, const int *lids)
+{
+  NG_FINALIZED(h);
+  return replace_rows(h, n, lids, 0.0, nullptr, nullptr);
+}
+
+extern "C" int nalu_gpu_load_complete(nalu_gpu_linsys *h)
+{
+  NG_FINALIZED(h);
+  // src/TpetraLinearSystem.C:1699,1706 export shared-not-owned rows to their owner.  Here
+  // every owned row was assembled completely by its owner (cut edges are duplicated on
+  // both sides), so there is nothing to move; only pending zeros are made real.
+  return materialize_zero(h);
+}
+
+// ---------------------------------------------------------- edge slots and colours
+__global__ void k_edge_slots(long long nEdges, const int *eL, const int *eR, int nOwned,
+                             const long long *sliceOff, const int *sliceWidth, const int *cols,
+                             int *slots)
+{
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nEdges) return;
+  const int L = eL[e], R = eR[e];
+  long long ll = -1, lr = -1, rl = -1, rr = -1;
+  if (L < nOwned) {
+    ll = find_in_row(sliceOff, sliceWidth, cols, L, L);
+    lr = find_in_row(sliceOff, sliceWidth, cols, L, R);
+  }
+  if (R < nOwned) {
+    rl = find_in_row(sliceOff, sliceWidth, cols, R, L);
+    rr = find_in_row(sliceOff, sliceWidth, cols, R, R);
+  }
+  slots[e] = (int)ll;
+  slots[nEdges + e] = (int)lr;
+  slots[2 * nEdges + e] = (int)rl;
+  slots[3 * nEdges + e] = (int)rr;
+}
+
+int nalu_gpu::ensure_edge_slots(nalu_gpu_linsys *h)
+{
+  if (h->dSlots || h->nEdges == 0) return NALU_GPU_OK;
+  NG_REQUIRE(h->sellSize < 2147483647LL, NALU_GPU_EUNSUPPORTED,
+             "edge-parallel scatter modes need < 2^31 matrix slots");
+  NG_HIP(hipMalloc(&h->dSlots, sizeof(int) * 4 * (size_t)h->nEdges));
+  const long long nb = (h->nEdges + 255) / 256;
+  k_edge_slots<<<(unsigned)nb, 256, 0, h->stream>>>(h->nEdges, h->dEdgeL, h->dEdgeR, h->nOwned,
+                                                     h->dSliceOff, h->dSliceWidth, h->dCols,
+                                                     h->dSlots);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+// greedy edge colouring on the host (set-up only): no two edges of one colour share a node
+int nalu_gpu::ensure_colors(nalu_gpu_linsys *h)
+{
+  if (h->dColorPerm || h->nEdges == 0) return NALU_GPU_OK;
+  const int64_t nE = h->nEdges;
+  std::vector<int> eL((size_t)nE), eR((size_t)nE);
+  NG_HIP(hipMemcpy(eL.data(), h->dEdgeL, sizeof(int) * (size_t)nE, hipMemcpyDeviceToHost));
+  NG_HIP(hipMemcpy(eR.data(), h->dEdgeR, sizeof(int) * (size_t)nE, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> used((size_t)h->nCols, 0);
+  std::vector<unsigned char> color((size_t)nE);
+  int nColors = 0;
+  for (int64_t e = 0; e < nE; ++e) {
+    const uint64_t m = used[eL[e]] | used[eR[e]];
+    NG_REQUIRE(m != ~0ull, NALU_GPU_EUNSUPPORTED, "more than 64 edge colours needed");
+    const int c = __builtin_ctzll(~m);
+    color[e] = (unsigned char)c;
+    used[eL[e]] |= 1ull << c;
+    used[eR[e]] |= 1ull << c;
+    nColors = std::max(nColors, c + 1);
+  }
+  h->nColors = nColors;
+  h->colorOff.assign((size_t)nColors + 1, 0);
+  for (int64_t e = 0; e < nE; ++e) h->colorOff[color[e] + 1]++;
+  for (int c = 0; c < nColors; ++c) h->colorOff[c + 1] += h->colorOff[c];
+  std::vector<int> perm((size_t)nE);
+  std::vector<int64_t> fill(h->colorOff.begin(), h->colorOff.end() - 1);
+  for (int64_t e = 0; e < nE; ++e) perm[fill[color[e]]++] = (int)e;
+  NG_HIP(hipMalloc(&h->dColorPerm, sizeof(int) * (size_t)nE));
+  NG_HIP(hipMemcpy(h->dColorPerm, perm.data(), sizeof(int) * (size_t)nE, hipMemcpyHostToDevice));
+  return NALU_GPU_OK;
+}
+
+// ------------------------------------------------------------------------- halo
+extern "C" int nalu_gpu_set_halo_plan(nalu_gpu_linsys *h, int n_nbr, const int *nbr_ranks,
+                                      const int *send_offsets, const int *send_lids,
+                                      const int *recv_offsets)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(n_nbr >= 0, NALU_GPU_EINVAL, "bad neighbour count");
+  NG_REQUIRE(n_nbr == 0 || (nbr_ranks && send_offsets && recv_offsets), NALU_GPU_EINVAL, "null plan");
+  const int64_t ns = n_nbr ? send_offsets[n_nbr] : 0, nr = n_nbr ? recv_offsets[n_nbr] : 0;
+  NG_REQUIRE(nr == h->nShared + h->nGhost, NALU_GPU_EINVAL,
+             "halo plan receives %lld values but there are %d shared+ghost columns",
+             (long long)nr, h->nShared + h->nGhost);
+  for (int64_t i = 0; i < ns; ++i)
+    NG_REQUIRE(send_lids[i] >= 0 && send_lids[i] < h->nOwned, NALU_GPU_EINVAL,
+               "send list entry %lld is not an owned row", (long long)i);
+  for (int p = 0; p < n_nbr; ++p)
+    NG_REQUIRE(send_offsets[p] <= send_offsets[p + 1] && recv_offsets[p] <= recv_offsets[p + 1],
+               NALU_GPU_EINVAL, "offsets must be non-decreasing");
+  NG_HIP(hipStreamSynchronize(h->stream));
+  NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf); NG_FREE(h->dRecvBuf);
+  h->nNbr = n_nbr;
+  h->nbrRanks.assign(nbr_ranks, nbr_ranks + n_nbr);
+  h->sendOff.assign(send_offsets, send_offsets + n_nbr + (n_nbr ? 1 : 0));
+  h->recvOff.assign(recv_offsets, recv_offsets + n_nbr + (n_nbr ? 1 : 0));
+  h->sendCount = ns;
+  h->recvCount = nr;
+  NG_HIP(hipMalloc(&h->dSendLids, sizeof(int) * (size_t)std::max<int64_t>(ns, 1)));
+  NG_HIP(hipMalloc(&h->dSendBuf, sizeof(double) * (size_t)std::max<int64_t>(ns, 1)));
+  NG_HIP(hipMalloc(&h->dRecvBuf, sizeof(double) * (size_t)std::max<int64_t>(nr, 1)));
+  if (ns) NG_HIP(hipMemcpy(h->dSendLids, send_lids, sizeof(int) * (size_t)ns, hipMemcpyHostToDevice));
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_set_comm(nalu_gpu_linsys *h, const nalu_gpu_comm *comm)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  if (!comm) {
+    h->hasComm = false;
+    return NALU_GPU_OK;
+  }
+  NG_REQUIRE(comm->allreduce_sum && comm->exchange_begin && comm->exchange_end, NALU_GPU_EINVAL,
+             "all three callbacks are required");
+  h->comm = *comm;
+  h->hasComm = true;
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_get_comm_buffers(nalu_gpu_linsys *h, double **send_buf, int64_t *send_count,
+                                         double **recv_buf, int64_t *recv_count,
+                                         double **reduce_buf, int *reduce_cap)
+{
+  NG_FINALIZED(h);
+  if (send_buf) *send_buf = h->dSendBuf;
+  if (send_count) *send_count = h->sendCount;
+  if (recv_buf) *recv_buf = h->dRecvBuf;
+  if (recv_count) *recv_count = h->recvCount;
+  if (reduce_buf) *reduce_buf = h->dReduce;
+  if (reduce_cap) *reduce_cap = REDUCE_CAP;
+  return NALU_GPU_OK;
+}
+
+__global__ void k_pack(long long n, const int *lids, const double *vec, double *buf)
+{
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) buf[i] = vec[lids[i]];
+}
+
+int nalu_gpu::halo_begin(nalu_gpu_linsys *h, const double *vec)
+{
+  if (h->nCols == h->nOwned) return NALU_GPU_OK;
+  NG_REQUIRE(h->hasComm && h->recvCount == h->nCols - h->nOwned, NALU_GPU_ESTATE,
+             "this system has %d shared/ghost columns: set_halo_plan and set_comm first",
+             h->nCols - h->nOwned);
+  if (h->sendCount)
+    k_pack<<<(unsigned)((h->sendCount + 255) / 256), 256, 0, h->stream>>>(h->sendCount, h->dSendLids,
+                                                                          vec, h->dSendBuf);
+  NG_HIP(hipGetLastError());
+  NG_REQUIRE(h->comm.exchange_begin(h->comm.ctx, h->stream) == 0, NALU_GPU_EHIP,
+             "exchange_begin callback failed");
+  return NALU_GPU_OK;
+}
+
+int nalu_gpu::halo_end(nalu_gpu_linsys *h, double *vec)
+{
+  if (h->nCols == h->nOwned) return NALU_GPU_OK;
+  NG_REQUIRE(h->comm.exchange_end(h->comm.ctx, h->stream) == 0, NALU_GPU_EHIP,
+             "exchange_end callback failed");
+  NG_HIP(hipMemcpyAsync(vec + h->nOwned, h->dRecvBuf, sizeof(double) * (size_t)h->recvCount,
+                        hipMemcpyDeviceToDevice, h->stream));
+  return NALU_GPU_OK;
+}
+
+int nalu_gpu::halo_exchange(nalu_gpu_linsys *h, double *vec)
+{
+  NG_TRY(halo_begin(h, vec));
+  return halo_end(h, vec);
+}
+
+extern "C" int nalu_gpu_halo_exchange(nalu_gpu_linsys *h, double *vec_dev)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(vec_dev, NALU_GPU_EINVAL, "null vector");
+  return halo_exchange(h, vec_dev);
+}

@@ -1,0 +1,198 @@
+// internal.hpp -- shared declarations of libnalu_gpu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "nalu_gpu.h"
+
+namespace nalu_gpu {
+
+// ---- matrix layout in HBM ---------------------------------------------------------
+// SELL-C (sliced ELLPACK), C = 256 rows per slice = one 256-thread workgroup (4 waves).
+// Entry k of row r lives at  sliceOff[r / C] + k * C + (r % C):
+// consecutive lanes touch consecutive addresses for every k (coalesced 512 B per wave
+// instruction for values, 256 B for columns), and the k-th entry of row r in the
+// Tpetra-ordered CSR (columns ascending) is the k-th entry here, so no CSR<->SELL
+// permutation table exists.  Slice width = longest row of the slice; padding entries
+// carry value 0 and column = own row.
+constexpr int SELL_C = 256;
+
+// per-entry edge tag (same layout as the values): edge id in bits 0..30, bit 31 set when
+// the row's node is the edge's R node.
+constexpr unsigned TAG_PAD = 0xFFFFFFFFu;   // padding
+constexpr unsigned TAG_DIAG = 0xFFFFFFFEu;  // the diagonal entry
+constexpr unsigned TAG_OTHER = 0xFFFFFFFDu; // graph entry that no edge maps to
+constexpr unsigned TAG_MAX_EDGE = 0x7FFFFFF0u;
+
+struct SellView {
+  const long long *sliceOff;
+  const int *sliceWidth;
+  const int *cols;
+  double *vals;
+  const unsigned *tags;
+  int nSlices;
+  int nRows;
+};
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+struct Timer {
+  std::vector<EventPair> pending;
+  double totalMs = 0.0;
+  long long count = 0;
+};
+
+constexpr int MAX_BLOCKS = 2048;  // capped grids: 256 CUs x 8 workgroups
+constexpr int REDUCE_CAP = 256;   // doubles in the reduce buffer
+constexpr int PARTIAL_SLOTS = 8;  // simultaneous reductions per kernel
+
+// device-resident solver scalars (one allocation, read by every solver kernel)
+struct SolverScalars {
+  double rz, rr0, r0norm, alpha, beta, tol, hn;
+  int iter, done, j, maxIter, histCap, pad;
+};
+
+}  // namespace nalu_gpu
+
+struct EntBlock {
+  int npe;
+  bool isEdge;
+  std::vector<int> nodes;
+};
+
+struct nalu_gpu_linsys {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool ownStream = false;
+  int numDof = 1;
+  int state = 0;  // 0 created, 1 under construction, 2 finalized
+  int nOwned = 0, nShared = 0, nGhost = 0, nCols = 0, myRank = 0;
+  std::vector<int64_t> gids;
+  std::vector<int> owners;
+  std::vector<EntBlock> blocks;
+  int64_t nEdges = 0;
+
+  // host CSR (Tpetra layout)
+  std::vector<int64_t> rowPtr;
+  std::vector<int> colIdx;
+  int64_t nnz = 0;
+
+  // device SELL
+  int nSlices = 0;
+  std::vector<long long> hSliceOff;
+  std::vector<int> hSliceWidth;
+  long long sellSize = 0;
+  long long *dSliceOff = nullptr;
+  int *dSliceWidth = nullptr;
+  int *dCols = nullptr;
+  double *dVals = nullptr;
+  unsigned *dTags = nullptr;
+
+  // edges
+  int *dEdgeL = nullptr, *dEdgeR = nullptr;
+  int *dSlots = nullptr;  // [4][nEdges] SELL positions LL, LR, RL, RR (-1: row not owned)
+  int nColors = 0;
+  std::vector<int64_t> colorOff;
+  int *dColorPerm = nullptr;
+
+  // vectors
+  double *dRhs = nullptr;   // nOwned
+  double *dX = nullptr;     // nCols
+  double *dDinv = nullptr;  // nCols
+  bool lazyZero = false;
+
+  // solver workspace
+  double *dR = nullptr, *dP = nullptr, *dQ = nullptr, *dW = nullptr, *dT = nullptr;
+  double *dV = nullptr;  // GMRES basis, (kspace+1) x nCols
+  int vCap = 0;
+  double *dPartials = nullptr;  // PARTIAL_SLOTS x MAX_BLOCKS
+  double *dReduce = nullptr;    // REDUCE_CAP
+  nalu_gpu::SolverScalars *dScal = nullptr;
+  double *dHist = nullptr;
+  int histCap = 0;
+  double *dH = nullptr, *dCs = nullptr, *dSn = nullptr, *dG = nullptr, *dY = nullptr;
+  int hCap = 0;
+  void *hPinned = nullptr;  // pinned host staging (4 KiB)
+  int *dList = nullptr;     // node-list staging for BC kernels
+  int64_t listCap = 0;
+
+  // halo
+  int nNbr = 0;
+  std::vector<int> nbrRanks, sendOff, recvOff;
+  int *dSendLids = nullptr;
+  double *dSendBuf = nullptr, *dRecvBuf = nullptr;
+  int64_t sendCount = 0, recvCount = 0;
+  nalu_gpu_comm comm{};
+  bool hasComm = false;
+
+  // timers
+  bool profiling = false;
+  nalu_gpu::Timer timers[NALU_GPU_T_COUNT];
+  std::vector<hipEvent_t> eventPool;
+};
+
+namespace nalu_gpu {
+
+int set_error(int code, const char *fmt, ...);
+
+#define NG_HIP(call)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return nalu_gpu::set_error(NALU_GPU_EHIP, "%s failed: %s (%s:%d)", #call,        \
+                                 hipGetErrorString(e_), __FILE__, __LINE__);           \
+  } while (0)
+
+#define NG_REQUIRE(cond, code, ...)                                   \
+  do {                                                                \
+    if (!(cond)) return nalu_gpu::set_error(code, __VA_ARGS__);       \
+  } while (0)
+
+#define NG_TRY(call)            \
+  do {                          \
+    int rc_ = (call);           \
+    if (rc_ != NALU_GPU_OK) return rc_; \
+  } while (0)
+
+inline SellView sell_view(const nalu_gpu_linsys *h)
+{
+  SellView v;
+  v.sliceOff = h->dSliceOff;
+  v.sliceWidth = h->dSliceWidth;
+  v.cols = h->dCols;
+  v.vals = h->dVals;
+  v.tags = h->dTags;
+  v.nSlices = h->nSlices;
+  v.nRows = h->nOwned;
+  return v;
+}
+
+// XCD-aware, bijective blockIdx -> slice map: workgroups are dealt round-robin over the 8
+// XCDs, so give each XCD one contiguous range of slices (neighbouring rows share an L2).
+__device__ __forceinline__ int xcd_slice(int b, int n)
+{
+  const int q = n >> 3, r = n & 7, xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+void timer_begin(nalu_gpu_linsys *h, int which);
+void timer_end(nalu_gpu_linsys *h, int which);
+int materialize_zero(nalu_gpu_linsys *h);
+int ensure_edge_slots(nalu_gpu_linsys *h);
+int ensure_colors(nalu_gpu_linsys *h);
+int ensure_list(nalu_gpu_linsys *h, int64_t n, const int *lids);
+int halo_exchange(nalu_gpu_linsys *h, double *vec);
+int halo_begin(nalu_gpu_linsys *h, const double *vec);
+int halo_end(nalu_gpu_linsys *h, double *vec);
+// reductions: kernels leave per-block partials in dPartials[slot][block]; this sums them
+// in a fixed order into dReduce[0..nslots) and (if a comm is set) all-reduces them.
+int finish_reduction(nalu_gpu_linsys *h, int nslots, int nblocks);
+int vec_grid(int64_t n);
+
+}  // namespace nalu_gpu

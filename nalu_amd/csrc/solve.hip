@@ -1,0 +1,677 @@
+// solve.hip -- SpMV, vector kernels, deterministic reductions and the device-resident
+// Jacobi-preconditioned CG / restarted right-preconditioned GMRES(m) (ICGS) of
+// libnalu_gpu.so (gfx950).  All kernels are HBM-bound fp64 streaming work: no MFMA.
+//
+// The Krylov loops never bring a scalar to the host: dot products end in a fixed-order
+// reduction of per-workgroup partials into the handle's reduce buffer, the scalar
+// recurrences (alpha, beta, Givens rotations, convergence test, residual history) run in
+// one-thread kernels on the device, and every kernel checks the device "done" flag, so the
+// host only polls that flag every few iterations and the iteration count is exact.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+#include "internal.hpp"
+
+using namespace nalu_gpu;
+
+namespace {
+
+// ------------------------------------------------------------------- reductions
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// fixed-order block sums (blockDim = 256): lane tree inside each wave, then the four
+// wave sums are added in order.
+template <int NS>
+__device__ __forceinline__ void block_sums(double (&v)[NS], double *partials, int nvalid)
+{
+  __shared__ double s[NS][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const double t = wave_sum(v[i]);
+    if (lane == 0) s[i][wave] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < NS && (int)threadIdx.x < nvalid) {
+    const int i = threadIdx.x;
+    partials[(size_t)i * MAX_BLOCKS + blockIdx.x] = ((s[i][0] + s[i][1]) + s[i][2]) + s[i][3];
+  }
+}
+
+// one workgroup per slot: fixed-order sum of the per-workgroup partials
+__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partials,
+                                                          int nblocks, double *__restrict__ out)
+{
+  __shared__ double s[256];
+  const double *p = partials + (size_t)blockIdx.x * MAX_BLOCKS;
+  double v = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) v += p[i];
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = s[0];
+}
+
+int reduce_partials(nalu_gpu_linsys *h, int nslots, int nblocks, int outOffset)
+{
+  k_reduce_partials<<<nslots, 256, 0, h->stream>>>(h->dPartials, nblocks, h->dReduce + outOffset);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+int allreduce(nalu_gpu_linsys *h, int count)
+{
+  if (!h->hasComm) return NALU_GPU_OK;
+  NG_REQUIRE(h->comm.allreduce_sum(h->comm.ctx, count, h->stream) == 0, NALU_GPU_EHIP,
+             "allreduce_sum callback failed");
+  return NALU_GPU_OK;
+}
+
+}  // namespace
+
+int nalu_gpu::vec_grid(int64_t n)
+{
+  const int64_t nb = (n + 1023) / 1024;  // ~4 elements per thread at least
+  return (int)std::max<int64_t>(1, std::min<int64_t>(nb, MAX_BLOCKS));
+}
+
+int nalu_gpu::finish_reduction(nalu_gpu_linsys *h, int nslots, int nblocks)
+{
+  NG_TRY(reduce_partials(h, nslots, nblocks, 0));
+  return allreduce(h, nslots);
+}
+
+namespace {
+
+// ------------------------------------------------------------------------- SpMV
+// y = A x on SELL-256: thread per row, lanes contiguous for every k.  Each workgroup owns a
+// contiguous chunk of slices (XCD-aware), optionally fusing the p.Ap partial sum (CG) or
+// the right-preconditioner column scaling x_c -> dinv_c x_c (GMRES).
+template <bool DOT, bool DINV>
+__global__ __launch_bounds__(SELL_C) void k_spmv(SellView A, const double *__restrict__ x,
+                                                  const double *__restrict__ dinv,
+                                                  double *__restrict__ y,
+                                                  double *__restrict__ partials,
+                                                  const SolverScalars *__restrict__ sc,
+                                                  int slicesPerBlock, int nChunks)
+{
+  if (sc && sc->done) return;
+  const int chunk = xcd_slice(blockIdx.x, nChunks);
+  const int s0 = chunk * slicesPerBlock;
+  const int s1 = min(A.nSlices, s0 + slicesPerBlock);
+  const int r = threadIdx.x;
+  double acc[1] = {0.0};
+  for (int s = s0; s < s1; ++s) {
+    const long long off = A.sliceOff[s];
+    const int w = A.sliceWidth[s];
+    const int row = s * SELL_C + r;
+    double sum = 0.0;
+    for (int k = 0; k < w; ++k) {
+      const long long pos = off + (long long)k * SELL_C + r;
+      const int c = A.cols[pos];
+      const double xv = DINV ? dinv[c] * x[c] : x[c];
+      sum += A.vals[pos] * xv;
+    }
+    if (row < A.nRows) {
+      y[row] = sum;
+      if (DOT) acc[0] += x[row] * sum;
+    }
+  }
+  if (DOT) block_sums<1>(acc, partials, 1);
+}
+
+struct SpmvGrid {
+  int nb, spb;
+};
+SpmvGrid spmv_grid(const nalu_gpu_linsys *h)
+{
+  SpmvGrid g;
+  const int nS = std::max(h->nSlices, 1);
+  g.spb = (nS + MAX_BLOCKS - 1) / MAX_BLOCKS;
+  g.nb = (nS + g.spb - 1) / g.spb;
+  return g;
+}
+
+template <bool DOT, bool DINV>
+int launch_spmv(nalu_gpu_linsys *h, const double *x, double *y, bool useDone, int *nblocks)
+{
+  const SpmvGrid g = spmv_grid(h);
+  if (nblocks) *nblocks = g.nb;
+  if (h->nSlices == 0) return NALU_GPU_OK;
+  timer_begin(h, NALU_GPU_T_SPMV);
+  k_spmv<DOT, DINV><<<g.nb, SELL_C, 0, h->stream>>>(sell_view(h), x, h->dDinv, y, h->dPartials,
+                                                     useDone ? h->dScal : nullptr, g.spb, g.nb);
+  timer_end(h, NALU_GPU_T_SPMV);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+// ------------------------------------------------------------------ vector kernels
+#define GRID_STRIDE(i, n) \
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+__global__ __launch_bounds__(256) void k_dot(long long n, const double *__restrict__ a,
+                                              const double *__restrict__ b,
+                                              double *__restrict__ partials)
+{
+  double acc[1] = {0.0};
+  GRID_STRIDE(i, n) acc[0] += a[i] * b[i];
+  block_sums<1>(acc, partials, 1);
+}
+
+__global__ __launch_bounds__(256) void k_axpy(long long n, double alpha, const double *__restrict__ x,
+                                               double *__restrict__ y)
+{
+  GRID_STRIDE(i, n) y[i] += alpha * x[i];
+}
+
+// dinv = 1/diag(A) (Ifpack2 Jacobi compute(): diagonal extraction), or 1 without precond
+__global__ __launch_bounds__(SELL_C) void k_extract_dinv(SellView A, int jacobi,
+                                                          double *__restrict__ dinv)
+{
+  const int slice = blockIdx.x, r = threadIdx.x;
+  const int row = slice * SELL_C + r;
+  if (row >= A.nRows) return;
+  double d = 1.0;
+  if (jacobi) {
+    const long long off = A.sliceOff[slice];
+    const int w = A.sliceWidth[slice];
+    d = 0.0;
+    for (int k = 0; k < w; ++k) {
+      const long long pos = off + (long long)k * SELL_C + r;
+      if (A.tags[pos] == TAG_DIAG) d = A.vals[pos];
+    }
+    d = 1.0 / d;
+  }
+  dinv[row] = d;
+}
+
+// ------------------------------------------------------------------------- CG
+__global__ __launch_bounds__(256) void k_cg_init(long long n, const double *__restrict__ b,
+                                                  const double *__restrict__ dinv,
+                                                  double *__restrict__ x, double *__restrict__ r,
+                                                  double *__restrict__ p,
+                                                  double *__restrict__ partials)
+{
+  double acc[2] = {0.0, 0.0};
+  GRID_STRIDE(i, n) {
+    const double ri = b[i];
+    const double zi = dinv[i] * ri;
+    x[i] = 0.0;
+    r[i] = ri;
+    p[i] = zi;
+    acc[0] += ri * zi;
+    acc[1] += ri * ri;
+  }
+  block_sums<2>(acc, partials, 2);
+}
+
+__global__ void k_cg_scal_init(SolverScalars *sc, const double *red, double *hist, double tol,
+                               int maxIter, int histCap)
+{
+  sc->rz = red[0];
+  sc->rr0 = red[1];
+  sc->r0norm = sqrt(red[1]);
+  sc->alpha = sc->beta = 0.0;
+  sc->tol = tol;
+  sc->iter = 0;
+  sc->j = 0;
+  sc->maxIter = maxIter;
+  sc->histCap = histCap;
+  sc->done = (sc->r0norm == 0.0) ? 1 : 0;
+  if (histCap > 0) hist[0] = 1.0;
+}
+
+__global__ void k_cg_scal_a(SolverScalars *sc, const double *red)
+{
+  if (sc->done) return;
+  sc->alpha = sc->rz / red[0];
+}
+
+__global__ __launch_bounds__(256) void k_cg_update(long long n, const SolverScalars *__restrict__ sc,
+                                                    const double *__restrict__ dinv,
+                                                    const double *__restrict__ p,
+                                                    const double *__restrict__ q,
+                                                    double *__restrict__ x, double *__restrict__ r,
+                                                    double *__restrict__ partials)
+{
+  if (sc->done) return;
+  const double alpha = sc->alpha;
+  double acc[2] = {0.0, 0.0};
+  GRID_STRIDE(i, n) {
+    x[i] += alpha * p[i];
+    const double ri = r[i] - alpha * q[i];
+    r[i] = ri;
+    acc[0] += ri * ri;
+    acc[1] += ri * (dinv[i] * ri);
+  }
+  block_sums<2>(acc, partials, 2);
+}
+
+__global__ void k_cg_scal_b(SolverScalars *sc, const double *red, double *hist)
+{
+  if (sc->done) return;
+  sc->iter += 1;
+  const double rel = sqrt(red[0]) / sc->r0norm;
+  if (sc->iter < sc->histCap) hist[sc->iter] = rel;
+  if (rel <= sc->tol || sc->iter >= sc->maxIter) {
+    sc->done = 1;
+    return;
+  }
+  sc->beta = red[1] / sc->rz;
+  sc->rz = red[1];
+}
+
+__global__ __launch_bounds__(256) void k_cg_p(long long n, const SolverScalars *__restrict__ sc,
+                                               const double *__restrict__ dinv,
+                                               const double *__restrict__ r, double *__restrict__ p)
+{
+  if (sc->done) return;
+  const double beta = sc->beta;
+  GRID_STRIDE(i, n) p[i] = dinv[i] * r[i] + beta * p[i];
+}
+
+// final true residual ||A x - b||^2 and ||b||^2 partials (src/LinearSolver.C:153-178;
+// src/TpetraLinearSystem.C:1756)
+__global__ __launch_bounds__(256) void k_resid_norms(long long n, const double *__restrict__ ax,
+                                                      const double *__restrict__ b,
+                                                      double *__restrict__ partials)
+{
+  double acc[2] = {0.0, 0.0};
+  GRID_STRIDE(i, n) {
+    const double d = ax[i] - b[i];
+    acc[0] += d * d;
+    acc[1] += b[i] * b[i];
+  }
+  block_sums<2>(acc, partials, 2);
+}
+
+// ------------------------------------------------------------------------ GMRES
+// w = b - q (q = A x), partial ||w||^2 ; cycle 0 passes q = nullptr (x0 = 0 => w = b)
+__global__ __launch_bounds__(256) void k_gm_resid(long long n, const double *__restrict__ b,
+                                                   const double *__restrict__ q,
+                                                   double *__restrict__ w, double *__restrict__ x,
+                                                   double *__restrict__ partials)
+{
+  double acc[1] = {0.0};
+  GRID_STRIDE(i, n) {
+    double wi;
+    if (q) wi = b[i] - q[i];
+    else { wi = b[i]; x[i] = 0.0; }
+    w[i] = wi;
+    acc[0] += wi * wi;
+  }
+  block_sums<1>(acc, partials, 1);
+}
+
+__global__ void k_gm_scal_begin(SolverScalars *sc, const double *red, double *hist, double *g,
+                                int m, int cycle, double tol, int maxIter, int histCap)
+{
+  const double beta = sqrt(red[0]);
+  if (cycle == 0) {
+    sc->r0norm = beta;
+    sc->rr0 = red[0];
+    sc->tol = tol;
+    sc->iter = 0;
+    sc->maxIter = maxIter;
+    sc->histCap = histCap;
+    sc->done = (beta == 0.0) ? 1 : 0;
+    if (histCap > 0) hist[0] = 1.0;
+  } else if (beta / sc->r0norm <= sc->tol) {
+    sc->done = 1;
+  }
+  sc->hn = beta;
+  sc->j = 0;
+  for (int i = 0; i <= m; ++i) g[i] = 0.0;
+  g[0] = beta;
+}
+
+// v = w / hn
+__global__ __launch_bounds__(256) void k_gm_scale(long long n, const SolverScalars *__restrict__ sc,
+                                                   const double *__restrict__ w,
+                                                   double *__restrict__ v)
+{
+  if (sc->done) return;
+  const double hn = sc->hn;
+  GRID_STRIDE(i, n) v[i] = w[i] / hn;
+}
+
+// up to 8 dot products V_{i0+t} . w in one pass over w
+__global__ __launch_bounds__(256) void k_gm_dots(long long n, const SolverScalars *__restrict__ sc,
+                                                  const double *__restrict__ V, long long ld, int i0,
+                                                  int nv, const double *__restrict__ w,
+                                                  double *__restrict__ partials)
+{
+  if (sc->done) return;
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  GRID_STRIDE(i, n) {
+    const double wv = w[i];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (t < nv) acc[t] += V[(long long)(i0 + t) * ld + i] * wv;
+  }
+  block_sums<8>(acc, partials, nv);
+}
+
+// w -= sum_i h_i V_i (i ascending, as the classical Gram-Schmidt update loop);
+// workgroup 0 also accumulates the Hessenberg column: H(:,j) (+)= h
+__global__ __launch_bounds__(256) void k_gm_update(long long n, const SolverScalars *__restrict__ sc,
+                                                    const double *__restrict__ V, long long ld,
+                                                    int nvec, const double *__restrict__ hred,
+                                                    double *__restrict__ w, double *__restrict__ Hcol,
+                                                    int first, double *__restrict__ partials,
+                                                    int wantNorm)
+{
+  if (sc->done) return;
+  double acc[1] = {0.0};
+  GRID_STRIDE(i, n) {
+    double wv = w[i];
+    for (int t = 0; t < nvec; ++t) wv -= hred[t] * V[(long long)t * ld + i];
+    w[i] = wv;
+    acc[0] += wv * wv;
+  }
+  if (blockIdx.x == 0)
+    for (int t = threadIdx.x; t < nvec; t += blockDim.x) Hcol[t] = first ? hred[t] : Hcol[t] + hred[t];
+  if (wantNorm) block_sums<1>(acc, partials, 1);
+}
+
+// Arnoldi step j bookkeeping: H(j+1,j), Givens rotations, implicit residual, history
+__global__ void k_gm_scal_step(SolverScalars *sc, const double *red, double *H, double *cs, double *sn,
+                               double *g, double *hist, int m, int j)
+{
+  if (sc->done) return;
+  const double hn = sqrt(red[0]);
+  double *hj = H + (size_t)j * (m + 1);
+  hj[j + 1] = hn;
+  sc->hn = hn;
+  for (int i = 0; i < j; ++i) {
+    const double t = cs[i] * hj[i] + sn[i] * hj[i + 1];
+    hj[i + 1] = -sn[i] * hj[i] + cs[i] * hj[i + 1];
+    hj[i] = t;
+  }
+  const double denom = sqrt(hj[j] * hj[j] + hj[j + 1] * hj[j + 1]);
+  cs[j] = hj[j] / denom;
+  sn[j] = hj[j + 1] / denom;
+  hj[j] = denom;
+  hj[j + 1] = 0.0;
+  g[j + 1] = -sn[j] * g[j];
+  g[j] = cs[j] * g[j];
+  sc->iter += 1;
+  sc->j = j + 1;
+  const double rel = fabs(g[j + 1]) / sc->r0norm;
+  if (sc->iter < sc->histCap) hist[sc->iter] = rel;
+  if (rel <= sc->tol || sc->iter >= sc->maxIter) sc->done = 1;
+}
+
+__global__ void k_gm_solve_y(const SolverScalars *sc, const double *H, const double *g, double *y, int m)
+{
+  const int jn = sc->j;
+  for (int i = jn - 1; i >= 0; --i) {
+    double s = g[i];
+    for (int k = i + 1; k < jn; ++k) s -= H[i + (size_t)k * (m + 1)] * y[k];
+    y[i] = s / H[i + (size_t)i * (m + 1)];
+  }
+}
+
+// x += dinv .* (sum_i y_i V_i)
+__global__ __launch_bounds__(256) void k_gm_update_x(long long n, const SolverScalars *__restrict__ sc,
+                                                      const double *__restrict__ V, long long ld,
+                                                      const double *__restrict__ y,
+                                                      const double *__restrict__ dinv,
+                                                      double *__restrict__ x)
+{
+  const int jn = sc->j;
+  GRID_STRIDE(i, n) {
+    double s = 0.0;
+    for (int t = 0; t < jn; ++t) s += y[t] * V[(long long)t * ld + i];
+    x[i] += dinv[i] * s;
+  }
+}
+
+int read_scalars(nalu_gpu_linsys *h, SolverScalars *out)
+{
+  NG_HIP(hipMemcpyAsync(h->hPinned, h->dScal, sizeof(SolverScalars), hipMemcpyDeviceToHost, h->stream));
+  NG_HIP(hipStreamSynchronize(h->stream));
+  *out = *(SolverScalars *)h->hPinned;
+  return NALU_GPU_OK;
+}
+
+int ensure_hist(nalu_gpu_linsys *h, int cap)
+{
+  if (cap <= h->histCap) return NALU_GPU_OK;
+  NG_HIP(hipStreamSynchronize(h->stream));
+  if (h->dHist) (void)hipFree(h->dHist);
+  NG_HIP(hipMalloc(&h->dHist, sizeof(double) * (size_t)cap));
+  h->histCap = cap;
+  return NALU_GPU_OK;
+}
+
+int solve_cg(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEvery)
+{
+  const long long n = h->nOwned;
+  const int vb = vec_grid(n);
+  k_cg_init<<<vb, 256, 0, h->stream>>>(n, h->dRhs, h->dDinv, h->dX, h->dR, h->dP, h->dPartials);
+  NG_HIP(hipGetLastError());
+  NG_TRY(finish_reduction(h, 2, vb));
+  k_cg_scal_init<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist, cfg->tolerance,
+                                         cfg->max_iterations, h->histCap);
+  SolverScalars sc;
+  for (int it = 0; it < cfg->max_iterations; ++it) {
+    int sb = 0;
+    NG_TRY(halo_exchange(h, h->dP));
+    NG_TRY((launch_spmv<true, false>(h, h->dP, h->dQ, true, &sb)));
+    NG_TRY(finish_reduction(h, 1, sb));
+    k_cg_scal_a<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
+    k_cg_update<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dDinv, h->dP, h->dQ, h->dX, h->dR, h->dPartials);
+    NG_TRY(finish_reduction(h, 2, vb));
+    k_cg_scal_b<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist);
+    k_cg_p<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dDinv, h->dR, h->dP);
+    NG_HIP(hipGetLastError());
+    if ((it + 1) % checkEvery == 0 && it + 1 < cfg->max_iterations) {
+      NG_TRY(read_scalars(h, &sc));
+      if (sc.done) break;
+    }
+  }
+  return NALU_GPU_OK;
+}
+
+int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEvery)
+{
+  const long long n = h->nOwned, ld = h->nCols;
+  const int m = cfg->kspace;
+  NG_REQUIRE(m >= 1 && m + 1 <= REDUCE_CAP, NALU_GPU_EINVAL, "kspace must be in [1,%d]", REDUCE_CAP - 1);
+  if (m + 1 > h->vCap) {
+    NG_HIP(hipStreamSynchronize(h->stream));
+    if (h->dV) (void)hipFree(h->dV);
+    h->dV = nullptr;
+    NG_HIP(hipMalloc(&h->dV, sizeof(double) * (size_t)(m + 1) * (size_t)std::max<long long>(ld, 1)));
+    NG_HIP(hipMemsetAsync(h->dV, 0, sizeof(double) * (size_t)(m + 1) * (size_t)std::max<long long>(ld, 1), h->stream));
+    h->vCap = m + 1;
+  }
+  if (m > h->hCap) {
+    NG_HIP(hipStreamSynchronize(h->stream));
+    if (h->dH) { (void)hipFree(h->dH); (void)hipFree(h->dCs); (void)hipFree(h->dSn); (void)hipFree(h->dG); (void)hipFree(h->dY); }
+    NG_HIP(hipMalloc(&h->dH, sizeof(double) * (size_t)(m + 1) * m));
+    NG_HIP(hipMalloc(&h->dCs, sizeof(double) * m));
+    NG_HIP(hipMalloc(&h->dSn, sizeof(double) * m));
+    NG_HIP(hipMalloc(&h->dG, sizeof(double) * (m + 1)));
+    NG_HIP(hipMalloc(&h->dY, sizeof(double) * m));
+    h->hCap = m;
+  }
+  const int vb = vec_grid(n);
+  SolverScalars sc;
+  int enq = 0;
+  for (int cycle = 0;; ++cycle) {
+    if (cycle == 0) {
+      k_gm_resid<<<vb, 256, 0, h->stream>>>(n, h->dRhs, nullptr, h->dW, h->dX, h->dPartials);
+    } else {
+      int sb = 0;
+      NG_TRY(halo_exchange(h, h->dX));
+      NG_TRY((launch_spmv<false, false>(h, h->dX, h->dQ, false, &sb)));
+      k_gm_resid<<<vb, 256, 0, h->stream>>>(n, h->dRhs, h->dQ, h->dW, h->dX, h->dPartials);
+    }
+    NG_HIP(hipGetLastError());
+    NG_TRY(finish_reduction(h, 1, vb));
+    k_gm_scal_begin<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist, h->dG, m, cycle,
+                                            cfg->tolerance, cfg->max_iterations, h->histCap);
+    k_gm_scale<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dW, h->dV);
+    NG_HIP(hipGetLastError());
+    NG_TRY(read_scalars(h, &sc));
+    if (sc.done) break;
+    bool stop = false;
+    for (int j = 0; j < m && enq < cfg->max_iterations; ++j, ++enq) {
+      double *vj = h->dV + (size_t)j * ld;
+      int sb = 0;
+      NG_TRY(halo_exchange(h, vj));
+      NG_TRY((launch_spmv<false, true>(h, vj, h->dW, true, &sb)));
+      double *Hcol = h->dH + (size_t)j * (m + 1);
+      for (int pass = 0; pass < 2; ++pass) {  // ICGS: two classical Gram-Schmidt passes
+        for (int i0 = 0; i0 <= j; i0 += 8) {
+          const int nv = std::min(8, j + 1 - i0);
+          k_gm_dots<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dV, ld, i0, nv, h->dW, h->dPartials);
+          NG_TRY(reduce_partials(h, nv, vb, i0));
+        }
+        NG_TRY(allreduce(h, j + 1));
+        k_gm_update<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dV, ld, j + 1, h->dReduce, h->dW, Hcol,
+                                               pass == 0, h->dPartials, pass == 1);
+      }
+      NG_HIP(hipGetLastError());
+      NG_TRY(finish_reduction(h, 1, vb));
+      k_gm_scal_step<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dH, h->dCs, h->dSn, h->dG,
+                                             h->dHist, m, j);
+      k_gm_scale<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dW, h->dV + (size_t)(j + 1) * ld);
+      NG_HIP(hipGetLastError());
+      if ((j + 1) % checkEvery == 0) {
+        NG_TRY(read_scalars(h, &sc));
+        if (sc.done) { stop = true; ++enq; break; }
+      }
+    }
+    k_gm_solve_y<<<1, 1, 0, h->stream>>>(h->dScal, h->dH, h->dG, h->dY, m);
+    k_gm_update_x<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dV, ld, h->dY, h->dDinv, h->dX);
+    NG_HIP(hipGetLastError());
+    NG_TRY(read_scalars(h, &sc));
+    if (stop || sc.done || sc.iter >= cfg->max_iterations) break;
+  }
+  return NALU_GPU_OK;
+}
+
+}  // namespace
+
+#define NG_FINALIZED(h)                                         \
+  do {                                                          \
+    NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");              \
+    NG_REQUIRE((h)->state == 2, NALU_GPU_ESTATE,                \
+               "linear system is not finalized");               \
+    NG_HIP(hipSetDevice((h)->device));                          \
+  } while (0)
+
+extern "C" int nalu_gpu_spmv(nalu_gpu_linsys *h, const double *x_dev, double *y_dev)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(x_dev && y_dev, NALU_GPU_EINVAL, "null vector");
+  NG_TRY(materialize_zero(h));
+  return launch_spmv<false, false>(h, x_dev, y_dev, false, nullptr);
+}
+
+extern "C" int nalu_gpu_dot(nalu_gpu_linsys *h, const double *a, const double *b, int64_t n, double *out)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(a && b && out && n >= 0, NALU_GPU_EINVAL, "bad dot arguments");
+  const int vb = vec_grid(n);
+  k_dot<<<vb, 256, 0, h->stream>>>(n, a, b, h->dPartials);
+  NG_HIP(hipGetLastError());
+  NG_TRY(finish_reduction(h, 1, vb));
+  NG_HIP(hipMemcpyAsync(h->hPinned, h->dReduce, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  NG_HIP(hipStreamSynchronize(h->stream));
+  *out = *(double *)h->hPinned;
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_norm2(nalu_gpu_linsys *h, const double *a, int64_t n, double *out)
+{
+  double d = 0.0;
+  NG_TRY(nalu_gpu_dot(h, a, a, n, &d));
+  *out = std::sqrt(d);
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_axpy(nalu_gpu_linsys *h, double alpha, const double *x, double *y, int64_t n)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(x && y && n >= 0, NALU_GPU_EINVAL, "bad axpy arguments");
+  k_axpy<<<vec_grid(n), 256, 0, h->stream>>>(n, alpha, x, y);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, double *x_out_dev,
+                              nalu_gpu_solve_info *info, double *history, int history_cap)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(cfg && info, NALU_GPU_EINVAL, "null config/info");
+  NG_REQUIRE(cfg->method == NALU_GPU_METHOD_CG || cfg->method == NALU_GPU_METHOD_GMRES,
+             NALU_GPU_EUNSUPPORTED, "solver method %d (supported: cg, gmres)", cfg->method);
+  NG_REQUIRE(cfg->precond == NALU_GPU_PRECOND_NONE || cfg->precond == NALU_GPU_PRECOND_JACOBI,
+             NALU_GPU_EUNSUPPORTED,
+             "preconditioner %d (supported: none, jacobi; the reference throws on unknown "
+             "names, src/LinearSolverConfig.C:97-99)", cfg->precond);
+  NG_REQUIRE(cfg->max_iterations >= 0 && cfg->tolerance >= 0.0, NALU_GPU_EINVAL, "bad solver limits");
+  NG_TRY(materialize_zero(h));
+  const int checkEvery = cfg->check_every > 0 ? cfg->check_every : 10;
+  NG_TRY(ensure_hist(h, cfg->max_iterations + 2));
+
+  // preconditioner_->compute() (src/LinearSolver.C:205), timed like timerPrecond_ (:195-211)
+  const auto t0 = std::chrono::steady_clock::now();
+  timer_begin(h, NALU_GPU_T_PRECOND);
+  if (h->nSlices)
+    k_extract_dinv<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), cfg->precond == NALU_GPU_PRECOND_JACOBI, h->dDinv);
+  NG_HIP(hipGetLastError());
+  NG_TRY(halo_exchange(h, h->dDinv));
+  timer_end(h, NALU_GPU_T_PRECOND);
+  NG_HIP(hipStreamSynchronize(h->stream));
+  const auto t1 = std::chrono::steady_clock::now();
+
+  timer_begin(h, NALU_GPU_T_SOLVE);
+  if (cfg->method == NALU_GPU_METHOD_CG) NG_TRY(solve_cg(h, cfg, checkEvery));
+  else NG_TRY(solve_gmres(h, cfg, checkEvery));
+  timer_end(h, NALU_GPU_T_SOLVE);
+
+  // residual_norm (src/LinearSolver.C:153-178) and ownedRhs_->norm2()
+  // (src/TpetraLinearSystem.C:1756); x gets its shared/ghost entries (sync_field :1753)
+  int sb = 0;
+  NG_TRY(halo_exchange(h, h->dX));
+  NG_TRY((launch_spmv<false, false>(h, h->dX, h->dQ, false, &sb)));
+  const int vb = vec_grid(h->nOwned);
+  k_resid_norms<<<vb, 256, 0, h->stream>>>(h->nOwned, h->dQ, h->dRhs, h->dPartials);
+  NG_HIP(hipGetLastError());
+  NG_TRY(finish_reduction(h, 2, vb));
+  double *pin = (double *)((char *)h->hPinned + 1024);
+  NG_HIP(hipMemcpyAsync(pin, h->dReduce, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  SolverScalars sc;
+  NG_TRY(read_scalars(h, &sc));
+  const auto t2 = std::chrono::steady_clock::now();
+  info->iters = sc.iter;
+  info->final_resid = std::sqrt(pin[0]);
+  info->rhs_norm2 = std::sqrt(pin[1]);
+  info->precond_seconds = std::chrono::duration<double>(t1 - t0).count();
+  info->solve_seconds = std::chrono::duration<double>(t2 - t1).count();
+  info->history_len = std::min(sc.iter + 1, h->histCap);
+  if (history && history_cap > 0) {
+    const int nh = std::min(info->history_len, history_cap);
+    NG_HIP(hipMemcpy(history, h->dHist, sizeof(double) * (size_t)nh, hipMemcpyDeviceToHost));
+    info->history_len = nh;
+  }
+  if (x_out_dev)
+    NG_HIP(hipMemcpyAsync(x_out_dev, h->dX, sizeof(double) * (size_t)h->nCols, hipMemcpyDeviceToDevice, h->stream));
+  NG_HIP(hipStreamSynchronize(h->stream));
+  return NALU_GPU_OK;
+}

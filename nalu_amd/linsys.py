@@ -1,0 +1,324 @@
+"""Host-side mirror of the reference's LinearSystem / TpetraLinearSolver surface
+(include/LinearSystem.h:40-168, include/LinearSolver.h:188-257) over the C ABI.
+
+Python is only the test/bench harness language here; every method forwards to one
+`nalu_gpu_*` entry point.  PyTorch supplies device memory and the stream handle."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _vec3(t):
+    """(3, n) contiguous fp64 device tensor -> nalu_gpu_vec3 of its rows (SoA)"""
+    assert t.dim() == 2 and t.shape[0] == 3 and t.is_contiguous() and t.dtype.is_floating_point
+    assert t.element_size() == 8
+    n = t.shape[1] * 8
+    p = t.data_ptr()
+    return L.Vec3(p, p + n, p + 2 * n)
+
+
+def _np(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class LinearSolverConfig:
+    """TpetraLinearSolverConfig (src/LinearSolverConfig.C:34-107); same keys and defaults."""
+
+    def __init__(self, name="solver", method="gmres", preconditioner="default", tolerance=1e-4,
+                 final_tolerance=None, max_iterations=50, kspace=50, output_level=0,
+                 write_matrix_files=False, check_every=0):
+        if preconditioner not in ("sgs", "mt_sgs", "jacobi", "default", "ilut", "riluk", "muelu",
+                                  "none", "chebyshev"):
+            # src/LinearSolverConfig.C:97-99
+            raise RuntimeError("invalid linear solver preconditioner specified ")
+        self.name, self.method, self.preconditioner = name, method, preconditioner
+        self.tolerance = tolerance
+        self.final_tolerance = tolerance if final_tolerance is None else final_tolerance
+        self.max_iterations, self.kspace = max_iterations, kspace
+        self.output_level, self.write_matrix_files = output_level, write_matrix_files
+        self.check_every = check_every
+
+    @classmethod
+    def from_dict(cls, node):
+        """One entry of the YAML `linear_solvers:` list, already parsed into a dict."""
+        keys = ("name", "method", "preconditioner", "tolerance", "final_tolerance",
+                "max_iterations", "kspace", "output_level", "write_matrix_files")
+        return cls(**{k: node[k] for k in keys if k in node})
+
+    def c_struct(self, is_final_outer_iter=False):
+        if self.method not in L.METHOD:
+            raise L.NaluGpuError(f"solver method '{self.method}' not supported (cg, gmres)")
+        if self.preconditioner not in L.PRECOND:
+            raise L.NaluGpuError(f"preconditioner '{self.preconditioner}' not supported on GPU")
+        tol = self.final_tolerance if is_final_outer_iter else self.tolerance
+        return L.SolverConfig(L.METHOD[self.method], L.PRECOND[self.preconditioner], tol,
+                              self.max_iterations, self.kspace, self.check_every)
+
+
+class GpuLinearSystem:
+    """One sierra::nalu::LinearSystem on one GPU."""
+
+    def __init__(self, num_dof=1, device=0, stream=None):
+        self.lib = L.load()
+        self.h = C.c_void_p()
+        L.check(self.lib.nalu_gpu_create(C.byref(self.h), device, num_dof,
+                                         C.c_void_p(stream) if stream else None))
+        self.num_dof = num_dof
+        self.device = device
+        self._comm_keepalive = None
+        # accessors of include/LinearSystem.h:129-139
+        self.linearSolveIterations = 0
+        self.linearResidual = 0.0
+        self.nonLinearResidual = 0.0
+        self.scaledNonLinearResidual = 0.0
+        self.firstNonLinearResidual = None
+        self.timer_precond = 0.0
+        self.history = np.zeros(0)
+
+    def close(self):
+        if self.h:
+            self.lib.nalu_gpu_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- graph ----------------------------------------------------------------
+    def beginLinearSystemConstruction(self, n_owned, n_shared=0, n_ghost=0, gids=None,
+                                      owners=None, my_rank=0):
+        n = n_owned + n_shared + n_ghost
+        gids = np.arange(1, n + 1, dtype=np.int64) if gids is None else _np(gids, np.int64)
+        assert len(gids) == n
+        own = None if owners is None else _np(owners, np.int32)
+        L.check(self.lib.nalu_gpu_begin_construction(
+            self.h, n_owned, n_shared, n_ghost, gids.ctypes.data,
+            None if own is None else own.ctypes.data, my_rank))
+        self.n_owned, self.n_shared, self.n_ghost, self.n_cols = n_owned, n_shared, n_ghost, n
+
+    def buildNodeGraph(self, node_lids):
+        a = _np(node_lids, np.int32)
+        L.check(self.lib.nalu_gpu_build_node_graph(self.h, len(a), a.ctypes.data))
+
+    def buildEdgeToNodeGraph(self, edge_nodes):
+        a = _np(edge_nodes, np.int32)
+        assert a.ndim == 2 and a.shape[1] == 2
+        L.check(self.lib.nalu_gpu_build_edge_to_node_graph(self.h, a.shape[0], a.ctypes.data))
+        self.n_edges = getattr(self, "n_edges", 0) + a.shape[0]
+
+    def buildElemToNodeGraph(self, elem_nodes):
+        a = _np(elem_nodes, np.int32)
+        L.check(self.lib.nalu_gpu_build_elem_to_node_graph(self.h, a.shape[0], a.shape[1],
+                                                           a.ctypes.data))
+
+    buildFaceToNodeGraph = buildElemToNodeGraph
+
+    def buildDirichletNodeGraph(self, node_lids):
+        a = _np(node_lids, np.int32)
+        L.check(self.lib.nalu_gpu_build_dirichlet_node_graph(self.h, len(a), a.ctypes.data))
+
+    def finalizeLinearSystem(self):
+        L.check(self.lib.nalu_gpu_finalize(self.h))
+        nr, nc, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(self.lib.nalu_gpu_get_sizes(self.h, C.byref(nr), C.byref(nc), C.byref(nnz)))
+        self.n_rows, self.n_cols, self.nnz = nr.value, nc.value, nnz.value
+
+    # ---- views ----------------------------------------------------------------
+    def graph(self):
+        rp = np.zeros(self.n_rows + 1, np.int64)
+        ci = np.zeros(max(self.nnz, 1), np.int32)
+        L.check(self.lib.nalu_gpu_get_graph(self.h, rp.ctypes.data, ci.ctypes.data))
+        return rp, ci[:self.nnz]
+
+    def matrix_values(self):
+        v = np.zeros(max(self.nnz, 1))
+        L.check(self.lib.nalu_gpu_get_matrix_values(self.h, v.ctypes.data))
+        return v[:self.nnz]
+
+    def set_matrix_values(self, v):
+        v = _np(v, np.float64)
+        assert len(v) == self.nnz
+        L.check(self.lib.nalu_gpu_set_matrix_values(self.h, v.ctypes.data))
+
+    def rhs(self):
+        b = np.zeros(max(self.n_rows, 1))
+        L.check(self.lib.nalu_gpu_get_rhs(self.h, b.ctypes.data))
+        return b[:self.n_rows]
+
+    def set_rhs(self, b):
+        b = _np(b, np.float64)
+        assert len(b) == self.n_rows
+        L.check(self.lib.nalu_gpu_set_rhs(self.h, b.ctypes.data))
+
+    def solution(self):
+        x = np.zeros(max(self.n_rows, 1))
+        L.check(self.lib.nalu_gpu_get_solution(self.h, x.ctypes.data))
+        return x[:self.n_rows]
+
+    # ---- assembly -------------------------------------------------------------
+    def zeroSystem(self):
+        L.check(self.lib.nalu_gpu_zero_system(self.h))
+
+    def sumInto(self, node_lids, rhs, lhs):
+        ids = _np(node_lids, np.int32)
+        r, m = _np(rhs, np.float64), _np(lhs, np.float64)
+        assert r.size == ids.size and m.size == ids.size ** 2
+        L.check(self.lib.nalu_gpu_sum_into(self.h, len(ids), ids.ctypes.data, r.ctypes.data,
+                                           m.ctypes.data))
+
+    def assemble_continuity_edges(self, coords, dpdx, vel, pressure, density, edge_area, dt,
+                                  gamma1=1.0, noc=1.0, interp_together=1.0, mode="rows"):
+        f = L.ContinuityFields(_vec3(coords), _vec3(dpdx), _vec3(vel), pressure.data_ptr(),
+                               density.data_ptr(), _vec3(edge_area))
+        self._check_fields(coords, dpdx, vel, pressure, density, edge_area=edge_area)
+        L.check(self.lib.nalu_gpu_assemble_continuity_edges(
+            self.h, C.byref(f), dt, gamma1, noc, interp_together, L.SCATTER[mode]))
+
+    def assemble_scalar_edges(self, coords, dqdx, vel, q, density, diff_flux_coeff, edge_area,
+                              mdot, alpha=0.0, alpha_upw=1.0, upw_factor=1.0, limiter=False,
+                              peclet="classic", hybrid_factor=0.0, tanh_c1=2.0, tanh_c2=4.0,
+                              mode="rows"):
+        """Option defaults are the reference's (src/SolutionOptions.C:32-51)."""
+        self._check_fields(coords, dqdx, vel, q, density, diff_flux_coeff, edge_area=edge_area,
+                           edge_scalar=mdot)
+        f = L.ScalarFields(_vec3(coords), _vec3(dqdx), _vec3(vel), q.data_ptr(),
+                           density.data_ptr(), diff_flux_coeff.data_ptr(), _vec3(edge_area),
+                           mdot.data_ptr())
+        o = L.ScalarOptions(alpha, alpha_upw, upw_factor, int(limiter), L.PECLET[peclet],
+                            hybrid_factor, tanh_c1, tanh_c2)
+        L.check(self.lib.nalu_gpu_assemble_scalar_edges(self.h, C.byref(f), C.byref(o),
+                                                        L.SCATTER[mode]))
+
+    def _check_fields(self, *node_fields, edge_area=None, edge_scalar=None):
+        # host-side shape checks: the kernels index n_cols nodes and n_edges edges
+        for t in node_fields:
+            assert t.shape[-1] >= self.n_cols and t.is_contiguous() and t.element_size() == 8, \
+                "nodal field smaller than the local node count"
+        ne = getattr(self, "n_edges", 0)
+        if edge_area is not None:
+            assert edge_area.shape[-1] >= ne
+        if edge_scalar is not None:
+            assert edge_scalar.shape[-1] >= ne and edge_scalar.is_contiguous()
+
+    def assemble_scalar_mass_be(self, q_n, q_np1, rho_n, rho_np1, dual_volume, dt):
+        self._check_fields(q_n, q_np1, rho_n, rho_np1, dual_volume)
+        L.check(self.lib.nalu_gpu_assemble_scalar_mass_be(
+            self.h, _ptr(q_n), _ptr(q_np1), _ptr(rho_n), _ptr(rho_np1), _ptr(dual_volume), dt))
+
+    def applyDirichletBCs(self, solution_field, bc_values_field, node_lids):
+        ids = _np(node_lids, np.int32)
+        self._check_fields(solution_field, bc_values_field)
+        L.check(self.lib.nalu_gpu_apply_dirichlet(self.h, len(ids), ids.ctypes.data,
+                                                  _ptr(solution_field), _ptr(bc_values_field)))
+
+    def resetRows(self, node_lids):
+        ids = _np(node_lids, np.int32)
+        L.check(self.lib.nalu_gpu_reset_rows(self.h, len(ids), ids.ctypes.data))
+
+    def loadComplete(self):
+        L.check(self.lib.nalu_gpu_load_complete(self.h))
+
+    # ---- solve ----------------------------------------------------------------
+    def solve(self, config, x_out=None, is_final_outer_iter=False, l2_scaling=1.0,
+              first_time_step_solve=True):
+        """TpetraLinearSystem::solve (src/TpetraLinearSystem.C:1709-1780)."""
+        cfg = config.c_struct(is_final_outer_iter)
+        info = L.SolveInfo()
+        hist = np.zeros(config.max_iterations + 2)
+        if x_out is not None:
+            assert x_out.numel() >= self.n_cols and x_out.is_contiguous()
+        L.check(self.lib.nalu_gpu_solve(self.h, C.byref(cfg), _ptr(x_out), C.byref(info),
+                                        hist.ctypes.data, len(hist)))
+        self.history = hist[:info.history_len].copy()
+        self.linearSolveIterations = info.iters
+        self.linearResidual = info.final_resid
+        self.nonLinearResidual = l2_scaling * info.rhs_norm2
+        if first_time_step_solve or self.firstNonLinearResidual is None:
+            self.firstNonLinearResidual = self.nonLinearResidual
+        self.scaledNonLinearResidual = self.nonLinearResidual / max(
+            np.finfo(float).eps, self.firstNonLinearResidual)
+        self.timer_precond = info.precond_seconds
+        self.solve_seconds = info.solve_seconds
+        return 0  # status is always 0 in the reference (src/LinearSolver.C:191)
+
+    # ---- building blocks ------------------------------------------------------
+    def spmv(self, x, y):
+        assert x.numel() >= self.n_cols and y.numel() >= self.n_rows
+        L.check(self.lib.nalu_gpu_spmv(self.h, _ptr(x), _ptr(y)))
+
+    def dot(self, a, b):
+        out = C.c_double()
+        n = min(a.numel(), b.numel())
+        L.check(self.lib.nalu_gpu_dot(self.h, _ptr(a), _ptr(b), n, C.byref(out)))
+        return out.value
+
+    def norm2(self, a):
+        out = C.c_double()
+        L.check(self.lib.nalu_gpu_norm2(self.h, _ptr(a), a.numel(), C.byref(out)))
+        return out.value
+
+    def axpy(self, alpha, x, y):
+        assert x.numel() == y.numel()
+        L.check(self.lib.nalu_gpu_axpy(self.h, alpha, _ptr(x), _ptr(y), x.numel()))
+
+    def compute_mdot_edges(self, coords, dpdx, vel, pressure, density, edge_area, dt, mdot_out,
+                           gamma1=1.0, noc=1.0, interp_together=1.0):
+        self._check_fields(coords, dpdx, vel, pressure, density, edge_area=edge_area,
+                           edge_scalar=mdot_out)
+        f = L.ContinuityFields(_vec3(coords), _vec3(dpdx), _vec3(vel), pressure.data_ptr(),
+                               density.data_ptr(), _vec3(edge_area))
+        L.check(self.lib.nalu_gpu_compute_mdot_edges(self.h, C.byref(f), dt, gamma1, noc,
+                                                     interp_together, _ptr(mdot_out)))
+
+    def nodal_grad_edges(self, edge_area, dual_volume, q, grad_out):
+        self._check_fields(dual_volume, q, edge_area=edge_area)
+        g = _vec3(grad_out)
+        assert grad_out.shape[1] >= self.n_rows
+        L.check(self.lib.nalu_gpu_nodal_grad_edges(self.h, _vec3(edge_area), _ptr(dual_volume),
+                                                   _ptr(q), g.x, g.y, g.z))
+
+    # ---- multi-GPU --------------------------------------------------------------
+    def set_halo_plan(self, neighbor_ranks, send_offsets, send_lids, recv_offsets):
+        nb = _np(neighbor_ranks, np.int32)
+        so, sl, ro = _np(send_offsets, np.int32), _np(send_lids, np.int32), _np(recv_offsets, np.int32)
+        L.check(self.lib.nalu_gpu_set_halo_plan(self.h, len(nb), nb.ctypes.data, so.ctypes.data,
+                                                sl.ctypes.data, ro.ctypes.data))
+
+    def comm_buffers(self):
+        sb, rb, red = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        sc, rc, cap = C.c_int64(), C.c_int64(), C.c_int()
+        L.check(self.lib.nalu_gpu_get_comm_buffers(self.h, C.byref(sb), C.byref(sc), C.byref(rb),
+                                                   C.byref(rc), C.byref(red), C.byref(cap)))
+        return (sb.value, sc.value), (rb.value, rc.value), (red.value, cap.value)
+
+    def set_comm(self, comm_struct):
+        self._comm_keepalive = comm_struct
+        L.check(self.lib.nalu_gpu_set_comm(self.h, C.byref(comm_struct) if comm_struct else None))
+
+    def halo_exchange(self, vec):
+        assert vec.numel() >= self.n_cols
+        L.check(self.lib.nalu_gpu_halo_exchange(self.h, _ptr(vec)))
+
+    # ---- timers ---------------------------------------------------------------
+    def set_profiling(self, on=True):
+        L.check(self.lib.nalu_gpu_set_profiling(self.h, int(on)))
+
+    def timer(self, name):
+        ms, cnt = C.c_double(), C.c_int64()
+        L.check(self.lib.nalu_gpu_get_timer(self.h, L.TIMERS[name], C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def reset_timers(self):
+        L.check(self.lib.nalu_gpu_reset_timers(self.h))
+
+    def synchronize(self):
+        L.check(self.lib.nalu_gpu_synchronize(self.h))

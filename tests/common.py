@@ -1,0 +1,74 @@
+"""Shared set-up for the parity tests: the same seeded inputs go to the CPU oracle and to
+the HIP library (through the C ABI)."""
+import numpy as np
+
+from fields import density, quadratic, velocity
+
+
+def dense(rp, ci, v, ncols):
+    A = np.zeros((len(rp) - 1, ncols))
+    for i in range(len(rp) - 1):
+        A[i, ci[rp[i]:rp[i + 1]]] = v[rp[i]:rp[i + 1]]
+    return A
+
+
+class Case:
+    """A box mesh with oracle geometry and the synthetic fields of SURVEY.md 8(d)."""
+
+    def __init__(self, oracle, n, perturb=0.0, variable_rho=True, dims=None):
+        self.o = oracle
+        dims = dims or (n, n, n)
+        self.m = m = oracle.BoxMesh(*dims, perturb=perturb)
+        self.vol, self.area = m.geometry()
+        self.p = quadratic(m.xyz, 0)
+        self.q = quadratic(m.xyz, 1)
+        self.dpdx = oracle.nodal_grad(m.edge_nodes, self.area, self.vol, self.p)
+        self.dqdx = oracle.nodal_grad(m.edge_nodes, self.area, self.vol, self.q)
+        self.vel = velocity(m.xyz)
+        self.rho = density(m.xyz, variable_rho)
+        self.gamma = 0.2 * np.ones(m.nnodes)
+        self.dt = 0.1
+        self.mdot = oracle.compute_mdot(m.edge_nodes, self.area, m.xyz, self.dpdx, self.vel,
+                                        self.p, self.rho, self.dt)
+
+    def oracle_system(self):
+        ls = self.o.LinSys(1, self.m.nnodes)
+        ls.add_connections(self.m.edge_nodes)
+        ls.finalize()
+        ls.zero()
+        return ls
+
+    def oracle_continuity(self, noc=1.0, interp=1.0, gamma1=1.0):
+        ls = self.oracle_system()
+        ls.assemble_continuity(self.m.edge_nodes, self.area, self.m.xyz, self.dpdx, self.vel,
+                               self.p, self.rho, self.dt, gamma1, noc, interp)
+        return ls
+
+    def oracle_scalar(self, **kw):
+        ls = self.oracle_system()
+        ls.assemble_scalar(self.m.edge_nodes, self.area, self.mdot, self.m.xyz, self.dqdx,
+                           self.vel, self.q, self.rho, self.gamma, self.o.scalar_opts(**kw))
+        return ls
+
+    # ---- device side ----
+    def dev(self, torch, device="cuda:0"):
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=device)
+        soa = lambda a: t(np.ascontiguousarray(a.T))
+        d = dict(coords=soa(self.m.xyz), dpdx=soa(self.dpdx), dqdx=soa(self.dqdx),
+                 vel=soa(self.vel), p=t(self.p), q=t(self.q), rho=t(self.rho),
+                 gamma=t(self.gamma), area=soa(self.area), mdot=t(self.mdot), vol=t(self.vol))
+        return d
+
+    def gpu_system(self, GpuLinearSystem):
+        g = GpuLinearSystem(1, 0)
+        g.beginLinearSystemConstruction(self.m.nnodes)
+        g.buildEdgeToNodeGraph(self.m.edge_nodes)
+        g.finalizeLinearSystem()
+        g.zeroSystem()
+        return g
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    den = np.abs(b).max()
+    return np.abs(a - b).max() / (den if den > 0 else 1.0)
