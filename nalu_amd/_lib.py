@@ -89,6 +89,9 @@ def load():
         raise NaluGpuError(
             f"{LIB_PATH} is missing: build it with `make -C nalu_amd/csrc` "
             "(or __graft_entry__.build()); nalu_amd has no CPU fallback")
+    # PyTorch-ROCm ships its own libamdhip64.so.7; import it first so that this library binds
+    # to the same HIP runtime instance (two runtimes in one process hide the GPU from torch).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.nalu_gpu_last_error.restype = C.c_char_p
     vp, i64, dbl, ci = C.c_void_p, C.c_int64, C.c_double, C.c_int
