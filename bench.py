@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+One *step* = one EquationSystem::assemble_and_solve pass of the continuity (pressure
+Poisson) system on a synthetic Hex8 box (src/EquationSystem.C:263-307 of the reference):
+  zeroSystem -> continuity edge assembly -> pin pressure node -> loadComplete ->
+  Jacobi-preconditioned CG with the reference regression's limits (tolerance 1e-5,
+  max_iterations 50: reg_tests/test_files/periodic3dEdge/periodic3dEdge.i:13-14).
+Inputs are resident in HBM before the timed region.  N > 1: weak scaling, every rank owns a
+z-slab of n x n x n nodes of an n x n x (n*N) box; halo exchange + all-reduce over RCCL.
+
+  python bench.py --gpus N --steps K --warmup W        (torchrun launches ranks for N > 1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def box_counts(nx, ny, nz):
+    N = nx * ny * nz
+    E = (nx - 1) * ny * nz + nx * (ny - 1) * nz + nx * ny * (nz - 1)
+    return N, E, N + 2 * E
+
+
+def build_rank(n, rank, nranks, device):
+    import torch
+    import nalu_amd
+    from nalu_amd import synth
+    S = nalu_amd.BoxSlab(n, n, n * nranks, rank, nranks, lengths=(1.0, 1.0, float(nranks)))
+    vol, area = S.uniform_geometry()
+    xyz = S.coords()
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=device)
+    F = dict(coords=t(xyz), dpdx=t(synth.quadratic_grad(xyz.T, 0).T), vel=t(synth.velocity(xyz.T).T),
+             p=t(synth.quadratic(xyz.T, 0)), rho=t(synth.density(xyz.T)), area=t(area))
+    g = nalu_amd.GpuLinearSystem(1, torch.device(device).index or 0,
+                                 torch.cuda.current_stream().cuda_stream)
+    g.beginLinearSystemConstruction(S.n_owned, S.n_shared, S.n_ghost, S.gids, S.owners, rank)
+    g.buildEdgeToNodeGraph(S.edge_nodes)
+    g.finalizeLinearSystem()
+    comm = None
+    if nranks > 1:
+        from nalu_amd.comm import TorchComm
+        g.set_halo_plan(S.neighbors, S.send_offsets, S.send_lids, S.recv_offsets)
+        comm = TorchComm(g, S.neighbors, S.send_offsets, S.recv_offsets, device)
+    return S, F, g, comm
+
+
+def cpu_baseline(n_cpu):
+    """The oracle ("port" of the reference algorithm: AoS gathers, per-edge sumInto with
+    sorted-row scan, CSR SpMV, Jacobi-CG) timed on one host core for ONE step on an
+    n_cpu^3 box -- a bounded sample of the same workload."""
+    import nalu_amd
+    from nalu_amd import synth
+    from oracle import pyoracle as po
+    po.build(fast=True)
+    S = nalu_amd.BoxSlab(n_cpu, n_cpu, n_cpu)
+    vol, area = S.uniform_geometry()
+    xyz = np.ascontiguousarray(S.coords().T)
+    p = synth.quadratic(xyz, 0)
+    dpdx = synth.quadratic_grad(xyz, 0)
+    vel, rho = synth.velocity(xyz), synth.density(xyz)
+    areaT = np.ascontiguousarray(area.T)
+    ls = po.LinSys(1, S.n_owned, fast=True)
+    ls.add_connections(S.edge_nodes)
+    ls.finalize()
+    t0 = time.perf_counter()
+    ls.zero()
+    ls.assemble_continuity(S.edge_nodes, areaT, xyz, dpdx, vel, p, rho, 0.1)
+    ls.reset_rows([0])
+    ls.sum_into([0], [0.0 - p[0]], [1.0])
+    t1 = time.perf_counter()
+    out = ls.solve("cg", "jacobi", tolerance=1e-5, max_iterations=50)
+    t2 = time.perf_counter()
+    return dict(value=S.n_edges / (t2 - t0), unit="edges/s", cores=1, kind="port",
+                sample=f"1 step (assemble + {out['iters']} Jacobi-CG its) on a {n_cpu}^3-node box, "
+                       f"oracle/nalu_oracle.c -O3 -march=native, 1 thread; "
+                       f"assemble {S.n_edges / (t1 - t0):.3e} edges/s, solve {(t2 - t1) * 1e3 / max(out['iters'], 1):.1f} ms/it")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=256, help="nodes per side of each GPU's slab")
+    ap.add_argument("--mode", default="rows", choices=["rows", "colored", "atomic"])
+    ap.add_argument("--cpu-n", type=int, default=128, help="box size of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--variants", action="store_true", help="also time the colored/atomic scatter variants")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    import nalu_amd
+    n = a.n
+    S, F, g, comm = build_rank(n, rank, world, device)
+    cfg = nalu_amd.LinearSolverConfig(method="cg", preconditioner="jacobi", tolerance=1e-5,
+                                      max_iterations=50, kspace=50)
+    pin = rank == 0
+    p0 = float(F["p"][0].item()) if pin else 0.0
+
+    def step(mode=a.mode):
+        g.zeroSystem()
+        g.assemble_continuity_edges(F["coords"], F["dpdx"], F["vel"], F["p"], F["rho"], F["area"],
+                                    0.1, 1.0, 1.0, 1.0, mode)
+        if pin:  # FixPressureAtNodeAlgorithm (src/FixPressureAtNodeAlgorithm.C:59-79)
+            g.resetRows([0])
+            g.sumInto([0], [0.0 - p0], [1.0])
+        g.loadComplete()
+        g.solve(cfg)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    g.set_profiling(True)
+    g.reset_timers()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    asm_ms, asm_cnt = g.timer("assemble_edges")
+    spmv_ms, spmv_cnt = g.timer("spmv")
+    solve_ms, _ = g.timer("solve")
+    iters = g.linearSolveIterations
+    g.set_profiling(False)
+
+    # algorithmic bytes: per-rank local sizes
+    Nl, El, nnzl = S.n_owned, S.n_edges, g.nnz
+    asm_bytes = 32 * El + 96 * Nl + 8 * nnzl
+    spmv_bytes = 12 * nnzl + 4 * (Nl + 1) + 16 * Nl
+    asm_t = asm_ms / max(asm_cnt, 1) * 1e-3
+    spmv_t = spmv_ms / max(spmv_cnt, 1) * 1e-3
+    Ng, Eg, _ = box_counts(n, n, n * world)
+
+    variants = {}
+    if a.variants and world == 1:
+        for mode in ("rows", "colored", "atomic"):
+            g.set_profiling(True)
+            g.reset_timers()
+            for _ in range(3):
+                g.zeroSystem()
+                g.assemble_continuity_edges(F["coords"], F["dpdx"], F["vel"], F["p"], F["rho"],
+                                            F["area"], 0.1, 1.0, 1.0, 1.0, mode)
+                g.loadComplete()
+            ms, cnt = g.timer("assemble_edges")
+            zms, zc = g.timer("zero")
+            variants[mode] = dict(assemble_ms=ms / cnt, zero_ms=zms / max(cnt, 1),
+                                  edges_per_s=El / ((ms + zms) / cnt * 1e-3))
+            g.set_profiling(False)
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "edges assembled/s + SpMV GB/s (% HBM peak), Hex8 256^3 Poisson, 1-8 GPUs",
+            "value": Eg * a.steps / dt, "unit": "edges/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"Hex8 box {n}^3 nodes per GPU ({n}x{n}x{n * world} total): continuity "
+                                   "edge assembly + pinned node + Jacobi-CG (tol 1e-5, max_it 50)",
+                       "nodes": Ng, "edges": Eg, "scatter": a.mode, "cg_iterations": iters,
+                       "parallelism": f"z-slabs x{world}"},
+            "roofline": {"kernel": "k_spmv<DOT> (SELL-256 SpMV fused with p.Ap)", "bound": "hbm",
+                         "achieved": spmv_bytes / spmv_t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": spmv_bytes / spmv_t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": spmv_bytes, "avg_ms": spmv_t * 1e3, "launches": spmv_cnt},
+            "roofline_assembly": {"kernel": f"k_assemble_rows<ContOp> ({a.mode})", "bound": "hbm",
+                                  "achieved": asm_bytes / asm_t / 1e9, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": asm_bytes / asm_t / 1e9 / HBM_PEAK_GBS,
+                                  "traffic": None, "algorithmic_bytes": asm_bytes,
+                                  "avg_ms": asm_t * 1e3, "launches": asm_cnt,
+                                  "edges_per_s_per_gpu": El / asm_t},
+            "solve_ms_per_iteration": solve_ms / a.steps / max(iters, 1),
+        }
+        if variants:
+            out["scatter_variants"] = variants
+        if world == 1 and a.cpu_n > 0:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_n)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    g.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
