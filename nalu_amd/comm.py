@@ -29,6 +29,21 @@ def wrap_device(ptr, n, device):
     return torch.as_tensor(_DevArray(ptr, n), device=device)
 
 
+def exchange_halo(send, recv, neighbors, send_offsets, recv_offsets, group=None):
+    """Post the neighbour sends/receives of one halo exchange; returns the work handles.
+    send[so[p]:so[p+1]] goes to neighbour p, recv[ro[p]:ro[p+1]] comes from it."""
+    ops = []
+    for n, p in enumerate(neighbors):
+        p = int(p)
+        a, b = int(send_offsets[n]), int(send_offsets[n + 1])
+        if b > a:
+            ops.append(dist.P2POp(dist.isend, send[a:b], p, group=group))
+        a, b = int(recv_offsets[n]), int(recv_offsets[n + 1])
+        if b > a:
+            ops.append(dist.P2POp(dist.irecv, recv[a:b], p, group=group))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
 class TorchComm:
     """Owns the ctypes callback struct for one GpuLinearSystem."""
 
@@ -44,6 +59,9 @@ class TorchComm:
         self.reduce = wrap_device(red, cap, device)
         self.pending = []
         self.errors = []
+        # gloo (tests: several ranks on one GPU) has no device send/recv: stage through the host
+        self.stage = dist.get_backend(group) == "gloo" and str(device).startswith("cuda")
+        self._recv_host = None
         self._ar = L.ALLREDUCE_FN(self._allreduce)
         self._xb = L.EXCHANGE_FN(self._exchange_begin)
         self._xe = L.EXCHANGE_FN(self._exchange_end)
@@ -53,7 +71,12 @@ class TorchComm:
     # callbacks must never raise through ctypes: record and return non-zero
     def _allreduce(self, ctx, count, stream):
         try:
-            dist.all_reduce(self.reduce[:count], op=dist.ReduceOp.SUM, group=self.group)
+            if self.stage:
+                t = self.reduce[:count].cpu()
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                self.reduce[:count].copy_(t)
+            else:
+                dist.all_reduce(self.reduce[:count], op=dist.ReduceOp.SUM, group=self.group)
             return 0
         except Exception as e:  # pragma: no cover
             self.errors.append(repr(e))
@@ -61,15 +84,11 @@ class TorchComm:
 
     def _exchange_begin(self, ctx, stream):
         try:
-            ops = []
-            for n, p in enumerate(self.neighbors):
-                if self.so[n + 1] > self.so[n]:
-                    ops.append(dist.P2POp(dist.isend, self.send[self.so[n]:self.so[n + 1]], p,
-                                          group=self.group))
-                if self.ro[n + 1] > self.ro[n]:
-                    ops.append(dist.P2POp(dist.irecv, self.recv[self.ro[n]:self.ro[n + 1]], p,
-                                          group=self.group))
-            self.pending = dist.batch_isend_irecv(ops) if ops else []
+            send, recv = self.send, self.recv
+            if self.stage:
+                send = self.send.cpu()
+                recv = self._recv_host = torch.empty(self.recv.shape, dtype=torch.float64)
+            self.pending = exchange_halo(send, recv, self.neighbors, self.so, self.ro, self.group)
             return 0
         except Exception as e:  # pragma: no cover
             self.errors.append(repr(e))
@@ -80,6 +99,8 @@ class TorchComm:
             for w in self.pending:
                 w.wait()
             self.pending = []
+            if self.stage:
+                self.recv.copy_(self._recv_host)
             return 0
         except Exception as e:  # pragma: no cover
             self.errors.append(repr(e))
