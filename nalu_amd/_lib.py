@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnalu_gpu.so")
+LIB_PATH = os.environ.get("NALU_GPU_LIB", os.path.join(_HERE, "libnalu_gpu.so"))
 
 SCATTER = {"rows": 0, "colored": 1, "atomic": 2}
 METHOD = {"cg": 0, "gmres": 1}

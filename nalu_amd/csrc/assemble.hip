@@ -32,11 +32,20 @@ struct ContOp {
     a.rho = P.f.density[n];
     return a;
   }
+  struct Edge {
+    double av[3];
+  };
+  __device__ static __forceinline__ Edge load_edge(const Params &P, long long e)
+  {
+    Edge E;
+    E.av[0] = P.f.edge_area.x[e]; E.av[1] = P.f.edge_area.y[e]; E.av[2] = P.f.edge_area.z[e];
+    return E;
+  }
   // src/AssembleContinuityEdgeSolverAlgorithm.C:163-203; returns tmdot
-  __device__ static __forceinline__ double flux(const Params &P, long long e, const Node &L,
+  __device__ static __forceinline__ double flux(const Params &P, const Edge &E, const Node &L,
                                                 const Node &R, double &lhsfac)
   {
-    const double av[3] = {P.f.edge_area.x[e], P.f.edge_area.y[e], P.f.edge_area.z[e]};
+    const double *av = E.av;
     const double om_interp = 1.0 - P.interp;
     double axdx = 0.0, asq = 0.0;
 #pragma unroll
@@ -63,11 +72,11 @@ struct ContOp {
     lhsfac = -asq * inv_axdx;
     return tmdot;
   }
-  __device__ static __forceinline__ void edge(const Params &P, long long e, const Node &L,
+  __device__ static __forceinline__ void edge(const Params &P, const Edge &E, const Node &L,
                                               const Node &R, double lhs[4], double rhs[2])
   {
     double lhsfac;
-    const double tmdot = flux(P, e, L, R, lhsfac);
+    const double tmdot = flux(P, E, L, R, lhsfac);
     lhs[0] = -lhsfac;
     lhs[1] = +lhsfac;
     rhs[0] = -tmdot / P.tau;
@@ -104,13 +113,23 @@ struct ScalOp {
   {
     return (2.0 * (dqm * dqp + fabs(dqm * dqp))) / ((dqm + dqp) * (dqm + dqp) + small);
   }
+  struct Edge {
+    double av[3], mdot;
+  };
+  __device__ static __forceinline__ Edge load_edge(const Params &P, long long e)
+  {
+    Edge E;
+    E.av[0] = P.f.edge_area.x[e]; E.av[1] = P.f.edge_area.y[e]; E.av[2] = P.f.edge_area.z[e];
+    E.mdot = P.f.mass_flow_rate[e];
+    return E;
+  }
   // src/AssembleScalarEdgeSolverAlgorithm.C:199-309
-  __device__ static __forceinline__ void edge(const Params &P, long long e, const Node &L,
+  __device__ static __forceinline__ void edge(const Params &P, const Edge &E, const Node &L,
                                               const Node &R, double lhs[4], double rhs[2])
   {
     const double small = 1.0e-16;
-    const double av[3] = {P.f.edge_area.x[e], P.f.edge_area.y[e], P.f.edge_area.z[e]};
-    const double tmdot = P.f.mass_flow_rate[e];
+    const double *av = E.av;
+    const double tmdot = E.mdot;
     const double alpha = P.o.alpha, alphaUpw = P.o.alpha_upw, hoUpwind = P.o.ho_upwind;
     const double om_alpha = 1.0 - alpha, om_alphaUpw = 1.0 - alphaUpw;
     double axdx = 0.0, asq = 0.0, udotx = 0.0;
@@ -208,7 +227,7 @@ template <class Op, bool SET>
 __global__ __launch_bounds__(SELL_C) void k_assemble_rows(SellView A, typename Op::Params P,
                                                            double *__restrict__ rhs)
 {
-  const int slice = xcd_slice(blockIdx.x, A.nSlices);
+  const int slice = sched_slice(A, blockIdx.x);
   const int r = threadIdx.x;
   const int row = slice * SELL_C + r;
   if (row >= A.nRows) return;
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(SELL_C) void k_assemble_rows(SellView A, typename O
     const bool isR = (tag >> 31) != 0;
     const typename Op::Node nb = Op::load(P, c);
     double lhs[4], rh[2];
-    Op::edge(P, e, select(isR, nb, own), select(isR, own, nb), lhs, rh);
+    Op::edge(P, Op::load_edge(P, e), select(isR, nb, own), select(isR, own, nb), lhs, rh);
     const double offd = isR ? lhs[2] : lhs[1];
     diag += isR ? lhs[3] : lhs[0];
     b += isR ? rh[1] : rh[0];
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(256) void k_assemble_edges(long long n, long long f
   const int L = eL[e], R = eR[e];
   const typename Op::Node nL = Op::load(P, L), nR = Op::load(P, R);
   double lhs[4], rh[2];
-  Op::edge(P, e, nL, nR, lhs, rh);
+  Op::edge(P, Op::load_edge(P, e), nL, nR, lhs, rh);
   const int sLL = slots[e], sLR = slots[nEdges + e], sRL = slots[2 * nEdges + e],
             sRR = slots[3 * nEdges + e];
   if (sLL >= 0) {
@@ -331,7 +350,7 @@ __global__ __launch_bounds__(256) void k_mdot(long long nEdges, const int *__res
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nEdges) return;
   double lhsfac;
-  mdot[e] = ContOp::flux(P, e, ContOp::load(P, eL[e]), ContOp::load(P, eR[e]), lhsfac);
+  mdot[e] = ContOp::flux(P, ContOp::load_edge(P, e), ContOp::load(P, eL[e]), ContOp::load(P, eR[e]), lhsfac);
 }
 
 // src/AssembleNodalGradEdgeAlgorithm.C:87-114 as a row gather (same summation order as the
@@ -343,7 +362,7 @@ __global__ __launch_bounds__(SELL_C) void k_nodal_grad(SellView A, nalu_gpu_vec3
                                                         double *__restrict__ gy,
                                                         double *__restrict__ gz)
 {
-  const int slice = xcd_slice(blockIdx.x, A.nSlices);
+  const int slice = sched_slice(A, blockIdx.x);
   const int r = threadIdx.x;
   const int row = slice * SELL_C + r;
   if (row >= A.nRows) return;

@@ -143,7 +143,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   drain_timers(h);
   for (hipEvent_t e : h->eventPool) (void)hipEventDestroy(e);
   NG_FREE(h->dSliceOff); NG_FREE(h->dSliceWidth); NG_FREE(h->dCols); NG_FREE(h->dVals);
-  NG_FREE(h->dTags); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
+  NG_FREE(h->dTags); NG_FREE(h->dOrder); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
   NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dReduce); NG_FREE(h->dScal);
@@ -432,6 +432,23 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
     NG_HIP(hipStreamSynchronize(h->stream));
     (void)hipFree(dRowPtr);
     (void)hipFree(dColIdx);
+  }
+
+  // experimental slice schedules (tuning knobs): NG_XCD=0 disables the
+  // per-XCD chunking; NG_TILE="ny,Z" orders line-slices (j + ny*k) in tiles of Z in k.
+  if (const char *e = getenv("NG_XCD")) h->xcdChunks = atoi(e);
+  if (const char *e = getenv("NG_TILE")) {
+    int ny = 0, Z = 0;
+    if (sscanf(e, "%d,%d", &ny, &Z) == 2 && ny > 0 && Z > 0 && h->nSlices % ny == 0) {
+      const int nz = h->nSlices / ny;
+      std::vector<int> ord;
+      ord.reserve((size_t)h->nSlices);
+      for (int kb = 0; kb < nz; kb += Z)
+        for (int j = 0; j < ny; ++j)
+          for (int k = kb; k < std::min(nz, kb + Z); ++k) ord.push_back(j + ny * k);
+      NG_HIP(hipMalloc(&h->dOrder, sizeof(int) * ord.size()));
+      NG_HIP(hipMemcpy(h->dOrder, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice));
+    }
   }
 
   // edges: SoA copy on the device + per-entry edge tags

@@ -34,6 +34,8 @@ struct SellView {
   const int *cols;
   double *vals;
   const unsigned *tags;
+  const int *order;  // slice schedule of the row kernels: workgroup p works on slice order[p]
+  int xcdChunks;     // 1: give each XCD a contiguous range of the schedule
   int nSlices;
   int nRows;
 };
@@ -93,6 +95,8 @@ struct nalu_gpu_linsys {
   int *dCols = nullptr;
   double *dVals = nullptr;
   unsigned *dTags = nullptr;
+  int *dOrder = nullptr;
+  int xcdChunks = 1;
 
   // edges
   int *dEdgeL = nullptr, *dEdgeR = nullptr;
@@ -168,6 +172,8 @@ inline SellView sell_view(const nalu_gpu_linsys *h)
   v.cols = h->dCols;
   v.vals = h->dVals;
   v.tags = h->dTags;
+  v.order = h->dOrder;
+  v.xcdChunks = h->xcdChunks;
   v.nSlices = h->nSlices;
   v.nRows = h->nOwned;
   return v;
@@ -179,6 +185,13 @@ __device__ __forceinline__ int xcd_slice(int b, int n)
 {
   const int q = n >> 3, r = n & 7, xcd = b & 7, idx = b >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// workgroup -> slice of the row-parallel kernels
+__device__ __forceinline__ int sched_slice(const SellView &A, int b)
+{
+  const int p = A.xcdChunks ? xcd_slice(b, A.nSlices) : b;
+  return A.order ? A.order[p] : p;
 }
 
 void timer_begin(nalu_gpu_linsys *h, int which);
