@@ -35,7 +35,8 @@ def build_rank(n, rank, nranks, device):
     import torch
     import nalu_amd
     from nalu_amd import synth
-    S = nalu_amd.BoxSlab(n, n, n * nranks, rank, nranks, lengths=(1.0, 1.0, float(nranks)))
+    S = nalu_amd.BoxSlab(n, n, n * nranks, rank, nranks, lengths=(1.0, 1.0, float(nranks)),
+                         edge_order=os.environ.get("NALU_EDGE_ORDER", "slot"))
     vol, area = S.uniform_geometry()
     xyz = S.coords()
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=device)

@@ -48,7 +48,7 @@ class BoxSlab:
     (src/TpetraLinearSystem.C:247-285, 1046-1074).  Local edges = every edge touching an
     owned node (cut edges are duplicated on both sides, see include/nalu_gpu.h)."""
 
-    def __init__(self, nxn, nyn, nzn, rank=0, nranks=1, lengths=(1.0, 1.0, 1.0)):
+    def __init__(self, nxn, nyn, nzn, rank=0, nranks=1, lengths=(1.0, 1.0, 1.0), edge_order="sorted"):
         assert nzn - 1 >= nranks, "need at least one element layer per rank"
         self.dims = (nxn, nyn, nzn)
         self.rank, self.nranks, self.lengths = rank, nranks, lengths
@@ -92,6 +92,12 @@ class BoxSlab:
         en, ed = box_edges(nxn, nyn, nzl)
         keep = own[en[:, 0]] | own[en[:, 1]]
         en, ed = en[keep], ed[keep]
+        if edge_order == "slot":
+            # slot-major: all first "upper" edges of the rows, then the second, ... (here:
+            # x-, y-, z-edges).  The k-th entries of consecutive rows then reference
+            # consecutive edges, so the edge-field gathers of the row kernels coalesce.
+            o = np.argsort(ed, kind="stable")
+            en, ed = en[o], ed[o]
         self.edge_nodes = np.ascontiguousarray(lid[en].astype(np.int32))
         self.edge_dir = ed
         self.n_edges = len(ed)

@@ -97,6 +97,11 @@ struct nalu_gpu_linsys {
   unsigned *dTags = nullptr;
   int *dOrder = nullptr;
   int xcdChunks = 1;
+  // slice chains of the marching assembly kernel (see k_assemble_chain)
+  int nChains = 0;
+  int *dChainOff = nullptr;     // nChains + 1
+  int *dChainSlices = nullptr;  // nSlices
+  bool useChains = false;
 
   // edges
   int *dEdgeL = nullptr, *dEdgeR = nullptr;
