@@ -146,7 +146,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dTags); NG_FREE(h->dOrder); NG_FREE(h->dChainOff); NG_FREE(h->dChainSlices); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
-  NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dReduce); NG_FREE(h->dScal);
+  NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   NG_FREE(h->dY); NG_FREE(h->dList); NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf);
   NG_FREE(h->dRecvBuf);
@@ -551,6 +551,7 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
   NG_HIP(hipMalloc(&h->dW, sizeof(double) * nC));
   NG_HIP(hipMalloc(&h->dT, sizeof(double) * nC));
   NG_HIP(hipMalloc(&h->dPartials, sizeof(double) * PARTIAL_SLOTS * MAX_BLOCKS));
+  NG_HIP(hipMalloc(&h->dSlicePartials, sizeof(double) * std::max(h->nSlices, 1)));
   NG_HIP(hipMalloc(&h->dReduce, sizeof(double) * REDUCE_CAP));
   NG_HIP(hipMalloc(&h->dScal, sizeof(SolverScalars)));
   NG_HIP(hipHostMalloc(&h->hPinned, 4096, hipHostMallocDefault));

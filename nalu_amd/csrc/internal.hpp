@@ -121,6 +121,7 @@ struct nalu_gpu_linsys {
   double *dV = nullptr;  // GMRES basis, (kspace+1) x nCols
   int vCap = 0;
   double *dPartials = nullptr;  // PARTIAL_SLOTS x MAX_BLOCKS
+  double *dSlicePartials = nullptr;  // nSlices: per-slice partials of the SpMV-fused dot
   double *dReduce = nullptr;    // REDUCE_CAP
   nalu_gpu::SolverScalars *dScal = nullptr;
   double *dHist = nullptr;
@@ -192,6 +193,18 @@ __device__ __forceinline__ int xcd_slice(int b, int n)
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// XCD-aware map with a single streaming front: runs of G consecutive items go to one XCD
+// (so neighbouring rows share an L2) and the eight XCDs advance through memory together.
+// G <= 0: identity.  Bijective on [0, n).
+__device__ __forceinline__ int xcd_run(int b, int n, int G)
+{
+  if (G <= 0) return b;
+  const int full = n / (8 * G) * (8 * G);
+  if (b >= full) return b;
+  const int xcd = b & 7, idx = b >> 3;
+  return ((idx / G) * 8 + xcd) * G + idx % G;
+}
+
 // workgroup -> slice of the row-parallel kernels
 __device__ __forceinline__ int sched_slice(const SellView &A, int b)
 {
@@ -210,7 +223,7 @@ int halo_begin(nalu_gpu_linsys *h, const double *vec);
 int halo_end(nalu_gpu_linsys *h, double *vec);
 // reductions: kernels leave per-block partials in dPartials[slot][block]; this sums them
 // in a fixed order into dReduce[0..nslots) and (if a comm is set) all-reduces them.
-int finish_reduction(nalu_gpu_linsys *h, int nslots, int nblocks);
+int finish_reduction(nalu_gpu_linsys *h, int nslots, int nblocks, const double *src = nullptr);
 int vec_grid(int64_t n);
 
 }  // namespace nalu_gpu
