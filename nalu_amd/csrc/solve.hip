@@ -46,34 +46,70 @@ __device__ __forceinline__ void block_sums(double (&v)[NS], double *partials, in
   }
 }
 
-// one workgroup per slot: fixed-order sum of the per-workgroup partials
-__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partials,
-                                                          int nblocks, double *__restrict__ out)
+// CG scalar recurrences (one thread).  They run either as the epilogue of the partial-sum
+// reduction (single rank) or as one-thread kernels behind the all-reduce (multi-rank).
+__device__ __forceinline__ void cg_scal_a(SolverScalars *sc, const double *red)
 {
-  __shared__ double s[256];
-  const double *p = partials + (size_t)blockIdx.x * MAX_BLOCKS;
-  double v = 0.0;
-  for (int i0 = threadIdx.x; i0 < nblocks; i0 += 256 * 8) {  // 8 loads in flight, same add order
-    double t[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = (i0 + u * 256 < nblocks) ? p[i0 + u * 256] : 0.0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v += t[u];
+  if (sc->done) return;
+  sc->alpha = sc->rz / red[0];
+}
+
+__device__ __forceinline__ void cg_scal_b(SolverScalars *sc, const double *red, double *hist)
+{
+  if (sc->done) return;
+  sc->iter += 1;
+  const double rel = sqrt(red[0]) / sc->r0norm;
+  if (sc->iter < sc->histCap) hist[sc->iter] = rel;
+  if (rel <= sc->tol || sc->iter >= sc->maxIter) {
+    sc->done = 1;
+    return;
   }
-  s[threadIdx.x] = v;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+  sc->beta = red[1] / sc->rz;
+  sc->rz = red[1];
+}
+
+enum { EPI_NONE = 0, EPI_CG_A = 1, EPI_CG_B = 2 };
+
+// one workgroup: fixed-order sum of the per-workgroup partials of every slot, then
+// (optionally) the scalar recurrence that consumes the sums
+constexpr int RED_T = 1024;
+template <int EPI>
+__global__ __launch_bounds__(RED_T) void k_reduce_partials(const double *__restrict__ partials,
+                                                          int nblocks, int nslots,
+                                                          double *__restrict__ out,
+                                                          SolverScalars *sc, double *hist)
+{
+  __shared__ double s[RED_T];
+  for (int slot = 0; slot < nslots; ++slot) {
+    const double *p = partials + (size_t)slot * MAX_BLOCKS;
+    double v = 0.0;
+    for (int i0 = threadIdx.x; i0 < nblocks; i0 += RED_T * 8) {  // 8 loads in flight, fixed add order
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = (i0 + u * RED_T < nblocks) ? p[i0 + u * RED_T] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = RED_T / 2; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[slot] = s[0];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = s[0];
+  if (EPI != EPI_NONE && threadIdx.x == 0) {  // thread 0 wrote out[] itself
+    if (EPI == EPI_CG_A) cg_scal_a(sc, out);
+    if (EPI == EPI_CG_B) cg_scal_b(sc, out, hist);
+  }
 }
 
 int reduce_partials(nalu_gpu_linsys *h, int nslots, int nblocks, int outOffset,
                     const double *src = nullptr)
 {
-  k_reduce_partials<<<nslots, 256, 0, h->stream>>>(src ? src : h->dPartials, nblocks,
-                                                   h->dReduce + outOffset);
+  k_reduce_partials<EPI_NONE><<<1, RED_T, 0, h->stream>>>(src ? src : h->dPartials, nblocks, nslots,
+                                                        h->dReduce + outOffset, nullptr, nullptr);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
 }
@@ -275,24 +311,20 @@ __global__ void k_cg_scal_init(SolverScalars *sc, const double *red, double *his
   if (histCap > 0) hist[0] = 1.0;
 }
 
-__global__ void k_cg_scal_a(SolverScalars *sc, const double *red)
-{
-  if (sc->done) return;
-  sc->alpha = sc->rz / red[0];
-}
+__global__ void k_cg_scal_a(SolverScalars *sc, const double *red) { cg_scal_a(sc, red); }
 
+// r -= alpha q with the partial sums of r.r and r.z; the x update waits for k_cg_p, which
+// reads p anyway (one vector read less per iteration)
 __global__ __launch_bounds__(256) void k_cg_update(long long n, const SolverScalars *__restrict__ sc,
                                                     const double *__restrict__ dinv,
-                                                    const double *__restrict__ p,
                                                     const double *__restrict__ q,
-                                                    double *__restrict__ x, double *__restrict__ r,
+                                                    double *__restrict__ r,
                                                     double *__restrict__ partials)
 {
   if (sc->done) return;
   const double alpha = sc->alpha;
   double acc[2] = {0.0, 0.0};
   GRID_STRIDE(i, n) {
-    x[i] += alpha * p[i];
     const double ri = r[i] - alpha * q[i];
     r[i] = ri;
     acc[0] += ri * ri;
@@ -303,25 +335,28 @@ __global__ __launch_bounds__(256) void k_cg_update(long long n, const SolverScal
 
 __global__ void k_cg_scal_b(SolverScalars *sc, const double *red, double *hist)
 {
-  if (sc->done) return;
-  sc->iter += 1;
-  const double rel = sqrt(red[0]) / sc->r0norm;
-  if (sc->iter < sc->histCap) hist[sc->iter] = rel;
-  if (rel <= sc->tol || sc->iter >= sc->maxIter) {
-    sc->done = 1;
-    return;
-  }
-  sc->beta = red[1] / sc->rz;
-  sc->rz = red[1];
+  cg_scal_b(sc, red, hist);
 }
 
+// x += alpha p_old ; p = z + beta p_old.  `it` is the host's iteration index: in the iteration
+// that set the done flag (sc->iter == it + 1) only x is finished; later launches return.
 __global__ __launch_bounds__(256) void k_cg_p(long long n, const SolverScalars *__restrict__ sc,
-                                               const double *__restrict__ dinv,
-                                               const double *__restrict__ r, double *__restrict__ p)
+                                               int it, const double *__restrict__ dinv,
+                                               const double *__restrict__ r, double *__restrict__ x,
+                                               double *__restrict__ p)
 {
-  if (sc->done) return;
+  const double alpha = sc->alpha;
+  if (sc->done) {
+    if (sc->iter != it + 1) return;
+    GRID_STRIDE(i, n) x[i] += alpha * p[i];
+    return;
+  }
   const double beta = sc->beta;
-  GRID_STRIDE(i, n) p[i] = dinv[i] * r[i] + beta * p[i];
+  GRID_STRIDE(i, n) {
+    const double pi = p[i];
+    x[i] += alpha * pi;
+    p[i] = dinv[i] * r[i] + beta * pi;
+  }
 }
 
 // final true residual ||A x - b||^2 and ||b||^2 partials (src/LinearSolver.C:153-178;
@@ -513,12 +548,22 @@ int solve_cg(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEve
     int sb = 0;
     NG_TRY(halo_exchange(h, h->dP));
     NG_TRY((launch_spmv<true, false>(h, h->dP, h->dQ, true, &sb)));
-    NG_TRY(finish_reduction(h, 1, sb, h->dSlicePartials));
-    k_cg_scal_a<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
-    k_cg_update<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dDinv, h->dP, h->dQ, h->dX, h->dR, h->dPartials);
-    NG_TRY(finish_reduction(h, 2, vb));
-    k_cg_scal_b<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist);
-    k_cg_p<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dDinv, h->dR, h->dP);
+    if (h->hasComm) {
+      NG_TRY(finish_reduction(h, 1, sb, h->dSlicePartials));
+      k_cg_scal_a<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
+    } else {
+      k_reduce_partials<EPI_CG_A><<<1, RED_T, 0, h->stream>>>(h->dSlicePartials, sb, 1, h->dReduce,
+                                                            h->dScal, nullptr);
+    }
+    k_cg_update<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dDinv, h->dQ, h->dR, h->dPartials);
+    if (h->hasComm) {
+      NG_TRY(finish_reduction(h, 2, vb));
+      k_cg_scal_b<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist);
+    } else {
+      k_reduce_partials<EPI_CG_B><<<1, RED_T, 0, h->stream>>>(h->dPartials, vb, 2, h->dReduce,
+                                                            h->dScal, h->dHist);
+    }
+    k_cg_p<<<vb, 256, 0, h->stream>>>(n, h->dScal, it, h->dDinv, h->dR, h->dX, h->dP);
     NG_HIP(hipGetLastError());
     if ((it + 1) % checkEvery == 0 && it + 1 < cfg->max_iterations) {
       NG_TRY(read_scalars(h, &sc));
