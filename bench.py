@@ -25,6 +25,17 @@ sys.path.insert(0, HERE)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic(n):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r1_traffic.json,
+    collected at n = 256 by scripts/pmc_short.sh): counters cannot be collected inside this
+    run, so `traffic` is only reported for the workload they were measured on."""
+    try:
+        d = json.load(open(os.path.join(HERE, "profiles", "r1_traffic.json")))
+    except OSError:
+        return {}
+    return d if d.get("n") == n else {}
+
+
 def box_counts(nx, ny, nz):
     N = nx * ny * nz
     E = (nx - 1) * ny * nz + nx * (ny - 1) * nz + nx * ny * (nz - 1)
@@ -180,6 +191,7 @@ def main():
 
     out = None
     if rank == 0:
+        pmc = pmc_traffic(n)
         out = {
             "metric": "edges assembled/s + SpMV GB/s (% HBM peak), Hex8 256^3 Poisson, 1-8 GPUs",
             "value": Eg * a.steps / dt, "unit": "edges/s",
@@ -192,12 +204,14 @@ def main():
                        "parallelism": f"z-slabs x{world}"},
             "roofline": {"kernel": "k_spmv<DOT> (SELL-256 SpMV fused with p.Ap)", "bound": "hbm",
                          "achieved": spmv_bytes / spmv_t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": spmv_bytes / spmv_t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": spmv_bytes / spmv_t / 1e9 / HBM_PEAK_GBS,
+                         "traffic": pmc.get("k_spmv", {}).get("hbm_bytes"),
                          "algorithmic_bytes": spmv_bytes, "avg_ms": spmv_t * 1e3, "launches": spmv_cnt},
             "roofline_assembly": {"kernel": f"k_assemble_rows<ContOp> ({a.mode})", "bound": "hbm",
                                   "achieved": asm_bytes / asm_t / 1e9, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": asm_bytes / asm_t / 1e9 / HBM_PEAK_GBS,
-                                  "traffic": None, "algorithmic_bytes": asm_bytes,
+                                  "traffic": pmc.get("k_assemble_rows", {}).get("hbm_bytes"),
+                                  "algorithmic_bytes": asm_bytes,
                                   "avg_ms": asm_t * 1e3, "launches": asm_cnt,
                                   "edges_per_s_per_gpu": El / asm_t},
             "solve_ms_per_iteration": solve_ms / a.steps / max(iters, 1),

@@ -264,95 +264,6 @@ __global__ __launch_bounds__(SELL_C) void k_assemble_rows(SellView A, typename O
   else rhs[row] += b;
 }
 
-// Marching variant of the row gather.  One workgroup walks a chain of slices s0, s1, ...
-// in which row r of s_{i+1} is a graph neighbour of row r of s_i (lattice-ordered meshes:
-// the same x-line, one plane up).  Each thread carries the nodal data of "its" row in the
-// previous, current and next slice in registers, and the current slice is shared through
-// LDS, so of the (up to) 6 neighbours of a lattice row only the 2 in the other lattice
-// direction are gathered from memory; every nodal datum is fetched once per chain instead
-// of once per neighbour.  The fabric traffic of the plain row kernel is ~3.7x the
-// algorithmic bytes at n = 256 (each line is re-fetched by its y/z neighbours after it has
-// left the 4 MiB L2); this kernel removes the z re-fetches.  Sources are chosen per entry by
-// comparing the column id, so the kernel is correct for any graph and any chain table;
-// arithmetic and summation order are identical to k_assemble_rows.
-template <class Op, bool SET>
-__global__ __launch_bounds__(SELL_C) void k_assemble_chain(SellView A, const int *__restrict__ chainOff,
-                                                            const int *__restrict__ chainSlices,
-                                                            int nChains, typename Op::Params P,
-                                                            double *__restrict__ rhs)
-{
-  using Node = typename Op::Node;
-  using Edge = typename Op::Edge;
-  constexpr int NF = sizeof(Node) / sizeof(double);
-  __shared__ double lds[NF * SELL_C];
-  const int chain = A.xcdChunks ? xcd_slice(blockIdx.x, nChains) : blockIdx.x;
-  const int i0 = chainOff[chain], i1 = chainOff[chain + 1];
-  const int r = threadIdx.x;
-  const int lastRow = A.nRows - 1;
-  int s = chainSlices[i0];
-  int row = s * SELL_C + r;
-  int rowPrev = -1;
-  Node cur = Op::load(P, min(row, lastRow));
-  Node prev = cur, next = cur;
-  for (int i = i0; i < i1; ++i) {
-    const int sN = (i + 1 < i1) ? chainSlices[i + 1] : -1;
-    const int rowNext = sN >= 0 ? sN * SELL_C + r : -1;
-    if (sN >= 0) next = Op::load(P, min(rowNext, lastRow));
-    __syncthreads();  // the previous step's LDS readers are done
-    {
-      const double *pc = reinterpret_cast<const double *>(&cur);
-#pragma unroll
-      for (int f = 0; f < NF; ++f) lds[f * SELL_C + r] = pc[f];
-    }
-    __syncthreads();
-    if (row < A.nRows) {
-      const long long off = A.sliceOff[s];
-      const int w = A.sliceWidth[s];
-      const int sBase = s * SELL_C;
-      double diag = 0.0, b = 0.0;
-      long long diagPos = -1;
-      for (int k = 0; k < w; ++k) {
-        const long long pos = off + (long long)k * SELL_C + r;
-        const unsigned tag = A.tags[pos];
-        if (tag >= TAG_OTHER) {
-          if (tag == TAG_DIAG) diagPos = pos;
-          else if (SET) A.vals[pos] = 0.0;
-          continue;
-        }
-        const int c = A.cols[pos];
-        const bool isR = (tag >> 31) != 0;
-        const Edge ed = Op::load_edge(P, tag & 0x7FFFFFFFu);
-        Node nb;
-        if (c == rowPrev) nb = prev;
-        else if (c == rowNext) nb = next;
-        else if ((unsigned)(c - sBase) < (unsigned)SELL_C) {
-          double *pn = reinterpret_cast<double *>(&nb);
-#pragma unroll
-          for (int f = 0; f < NF; ++f) pn[f] = lds[f * SELL_C + (c - sBase)];
-        } else nb = Op::load(P, c);
-        double lhs[4], rh[2];
-        Op::edge(P, ed, select(isR, nb, cur), select(isR, cur, nb), lhs, rh);
-        const double offd = isR ? lhs[2] : lhs[1];
-        diag += isR ? lhs[3] : lhs[0];
-        b += isR ? rh[1] : rh[0];
-        if (SET) A.vals[pos] = offd;
-        else A.vals[pos] += offd;
-      }
-      if (diagPos >= 0) {
-        if (SET) A.vals[diagPos] = diag;
-        else A.vals[diagPos] += diag;
-      }
-      if (SET) rhs[row] = b;
-      else rhs[row] += b;
-    }
-    prev = cur;
-    cur = next;
-    rowPrev = row;
-    s = sN;
-    row = rowNext;
-  }
-}
-
 __device__ __forceinline__ void add_plain(double *p, double v) { *p += v; }
 __device__ __forceinline__ void add_atomic(double *p, double v) { unsafeAtomicAdd(p, v); }
 
@@ -398,15 +309,8 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
     const bool set = h->lazyZero;
     h->lazyZero = false;
     timer_begin(h, NALU_GPU_T_ASSEMBLE_EDGES);
-    if (h->useChains) {
-      if (set) k_assemble_chain<Op, true><<<h->nChains, SELL_C, 0, h->stream>>>(
-          sell_view(h), h->dChainOff, h->dChainSlices, h->nChains, P, h->dRhs);
-      else k_assemble_chain<Op, false><<<h->nChains, SELL_C, 0, h->stream>>>(
-          sell_view(h), h->dChainOff, h->dChainSlices, h->nChains, P, h->dRhs);
-    } else {
-      if (set) k_assemble_rows<Op, true><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), P, h->dRhs);
-      else k_assemble_rows<Op, false><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), P, h->dRhs);
-    }
+    if (set) k_assemble_rows<Op, true><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), P, h->dRhs);
+    else k_assemble_rows<Op, false><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), P, h->dRhs);
     timer_end(h, NALU_GPU_T_ASSEMBLE_EDGES);
     NG_HIP(hipGetLastError());
     return NALU_GPU_OK;

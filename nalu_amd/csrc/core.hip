@@ -143,7 +143,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   drain_timers(h);
   for (hipEvent_t e : h->eventPool) (void)hipEventDestroy(e);
   NG_FREE(h->dSliceOff); NG_FREE(h->dSliceWidth); NG_FREE(h->dCols); NG_FREE(h->dVals);
-  NG_FREE(h->dTags); NG_FREE(h->dOrder); NG_FREE(h->dChainOff); NG_FREE(h->dChainSlices); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
+  NG_FREE(h->dTags); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
   NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dReduce); NG_FREE(h->dScal);
@@ -434,77 +434,8 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
     (void)hipFree(dColIdx);
   }
 
-  // experimental slice schedules (tuning knobs): NG_XCD=0 disables the
-  // per-XCD chunking; NG_TILE="ny,Z" orders line-slices (j + ny*k) in tiles of Z in k.
-  if (const char *e = getenv("NG_XCD")) h->xcdChunks = atoi(e);
-  if (const char *e = getenv("NG_TILE")) {
-    int ny = 0, Z = 0;
-    if (sscanf(e, "%d,%d", &ny, &Z) == 2 && ny > 0 && Z > 0 && h->nSlices % ny == 0) {
-      const int nz = h->nSlices / ny;
-      std::vector<int> ord;
-      ord.reserve((size_t)h->nSlices);
-      for (int kb = 0; kb < nz; kb += Z)
-        for (int j = 0; j < ny; ++j)
-          for (int k = kb; k < std::min(nz, kb + Z); ++k) ord.push_back(j + ny * k);
-      NG_HIP(hipMalloc(&h->dOrder, sizeof(int) * ord.size()));
-      NG_HIP(hipMemcpy(h->dOrder, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice));
-    }
-  }
-
-  // Slice chains for the marching assembly kernel: chain = s0, s1, ... where (nearly) every
-  // row r of s_i has row r + 256*(s_{i+1}-s_i) of s_{i+1} among its columns (on lattice-
-  // ordered meshes: the same x-line one plane up).  One workgroup walks a chain and carries
-  // the nodal data of the previous / next slice in registers.
-  {
-    const int nS = h->nSlices;
-    std::vector<int> next((size_t)std::max(nS, 1), -1);
-    parallel_for(nS, [&](int64_t a, int64_t b) {
-      std::vector<std::pair<int, int>> votes;
-      for (int64_t s = a; s < b; ++s) {
-        votes.clear();
-        const int r1 = std::min(nO, (int)(s + 1) * SELL_C);
-        for (int r = (int)s * SELL_C; r < r1; ++r)
-          for (int64_t k = h->rowPtr[r]; k < h->rowPtr[r + 1]; ++k) {
-            const int c = h->colIdx[k];
-            if (c >= nO || c % SELL_C != r % SELL_C || c / SELL_C <= s) continue;
-            const int t = c / SELL_C;
-            bool found = false;
-            for (auto &v : votes)
-              if (v.first == t) { ++v.second; found = true; break; }
-            if (!found) votes.emplace_back(t, 1);
-          }
-        int best = -1, bv = SELL_C / 2 - 1;
-        for (auto &v : votes)
-          if (v.second > bv || (v.second == bv && v.first > best)) { best = v.first; bv = v.second; }
-        next[s] = best;
-      }
-    });
-    int Lc = std::max(4, std::min(64, nS / MAX_BLOCKS));
-    if (const char *e = getenv("NG_CHAIN_LEN")) Lc = std::max(1, atoi(e));
-    std::vector<char> seen((size_t)std::max(nS, 1), 0);
-    std::vector<int> chainOff(1, 0), chainSlices;
-    chainSlices.reserve((size_t)nS);
-    for (int s = 0; s < nS; ++s) {
-      if (seen[s]) continue;
-      int cur = s, len = 0;
-      while (cur >= 0 && !seen[cur] && len < Lc) {
-        seen[cur] = 1;
-        chainSlices.push_back(cur);
-        ++len;
-        cur = next[cur];
-      }
-      chainOff.push_back((int)chainSlices.size());
-    }
-    h->nChains = (int)chainOff.size() - 1;
-    h->useChains = nS >= 64 && h->nChains * 2 <= nS;
-    if (const char *e = getenv("NG_CHAIN")) h->useChains = atoi(e) != 0 && nS > 0;
-    if (nS > 0) {
-      NG_HIP(hipMalloc(&h->dChainOff, sizeof(int) * chainOff.size()));
-      NG_HIP(hipMalloc(&h->dChainSlices, sizeof(int) * chainSlices.size()));
-      NG_HIP(hipMemcpy(h->dChainOff, chainOff.data(), sizeof(int) * chainOff.size(), hipMemcpyHostToDevice));
-      NG_HIP(hipMemcpy(h->dChainSlices, chainSlices.data(), sizeof(int) * chainSlices.size(), hipMemcpyHostToDevice));
-    }
-  }
+  // slice schedule of the row kernels (tuning knob)
+  if (const char *e = getenv("NG_XCD_RUN")) h->xcdRun = atoi(e);
 
   // edges: SoA copy on the device + per-entry edge tags
   if (h->nEdges > 0) {

@@ -34,8 +34,7 @@ struct SellView {
   const int *cols;
   double *vals;
   const unsigned *tags;
-  const int *order;  // slice schedule of the row kernels: workgroup p works on slice order[p]
-  int xcdChunks;     // 1: give each XCD a contiguous range of the schedule
+  int xcdRun;  // slice schedule of the row kernels (xcd_run): slices per XCD run, 0 = identity
   int nSlices;
   int nRows;
 };
@@ -95,13 +94,7 @@ struct nalu_gpu_linsys {
   int *dCols = nullptr;
   double *dVals = nullptr;
   unsigned *dTags = nullptr;
-  int *dOrder = nullptr;
-  int xcdChunks = 1;
-  // slice chains of the marching assembly kernel (see k_assemble_chain)
-  int nChains = 0;
-  int *dChainOff = nullptr;     // nChains + 1
-  int *dChainSlices = nullptr;  // nSlices
-  bool useChains = false;
+  int xcdRun = 8;  // slices per XCD run of the row-kernel schedule (NG_XCD_RUN)
 
   // edges
   int *dEdgeL = nullptr, *dEdgeR = nullptr;
@@ -178,24 +171,17 @@ inline SellView sell_view(const nalu_gpu_linsys *h)
   v.cols = h->dCols;
   v.vals = h->dVals;
   v.tags = h->dTags;
-  v.order = h->dOrder;
-  v.xcdChunks = h->xcdChunks;
+  v.xcdRun = h->xcdRun;
   v.nSlices = h->nSlices;
   v.nRows = h->nOwned;
   return v;
 }
 
-// XCD-aware, bijective blockIdx -> slice map: workgroups are dealt round-robin over the 8
-// XCDs, so give each XCD one contiguous range of slices (neighbouring rows share an L2).
-__device__ __forceinline__ int xcd_slice(int b, int n)
-{
-  const int q = n >> 3, r = n & 7, xcd = b & 7, idx = b >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-// XCD-aware map with a single streaming front: runs of G consecutive items go to one XCD
-// (so neighbouring rows share an L2) and the eight XCDs advance through memory together.
-// G <= 0: identity.  Bijective on [0, n).
+// XCD-aware, bijective blockIdx -> item map with a single streaming front.  Workgroups are
+// dealt round-robin over the 8 XCDs; runs of G consecutive items go to one XCD (so
+// neighbouring rows share an L2) while the eight XCDs advance through memory together.
+// (Giving each XCD one contiguous eighth of the matrix instead costs 15-25 % of the HBM
+// rate on MI355X: eight separate fronts.)  G <= 0: identity.
 __device__ __forceinline__ int xcd_run(int b, int n, int G)
 {
   if (G <= 0) return b;
@@ -208,8 +194,7 @@ __device__ __forceinline__ int xcd_run(int b, int n, int G)
 // workgroup -> slice of the row-parallel kernels
 __device__ __forceinline__ int sched_slice(const SellView &A, int b)
 {
-  const int p = A.xcdChunks ? xcd_slice(b, A.nSlices) : b;
-  return A.order ? A.order[p] : p;
+  return xcd_run(b, A.nSlices, A.xcdRun);
 }
 
 void timer_begin(nalu_gpu_linsys *h, int which);

@@ -213,13 +213,6 @@ __global__ __launch_bounds__(SELL_C) void k_spmv(SellView A, const double *__res
   if (DOT) block_sums<1>(acc, partials, 1, s);
 }
 
-int spmv_run()
-{
-  static int run = -1;
-  if (run < 0) run = getenv("NG_SPMV_RUN") ? atoi(getenv("NG_SPMV_RUN")) : 16;
-  return run;
-}
-
 // DOT: the partials land in h->dSlicePartials[0 .. *nblocks)
 template <bool DOT, bool DINV>
 int launch_spmv(nalu_gpu_linsys *h, const double *x, double *y, bool useDone, int *nblocks)
@@ -229,7 +222,7 @@ int launch_spmv(nalu_gpu_linsys *h, const double *x, double *y, bool useDone, in
   timer_begin(h, NALU_GPU_T_SPMV);
   k_spmv<DOT, DINV><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), x, h->dDinv, y,
                                                            h->dSlicePartials,
-                                                           useDone ? h->dScal : nullptr, spmv_run());
+                                                           useDone ? h->dScal : nullptr, h->xcdRun);
   timer_end(h, NALU_GPU_T_SPMV);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;

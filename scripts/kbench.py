@@ -10,8 +10,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 S, F, g, _ = build_rank(n, 0, 1, "cuda:0")
 res = {"lib": os.path.basename(nalu_amd.LIB_PATH), "n": n}
 for mode in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["rows"]):
-    g.set_profiling(True); g.reset_timers()
-    for _ in range(5):
+    g.set_profiling(True)
+    for rep in range(7):
+        if rep == 2: g.reset_timers()  # two warm-up passes
         g.zeroSystem()
         g.assemble_continuity_edges(F["coords"], F["dpdx"], F["vel"], F["p"], F["rho"], F["area"], 0.1, 1.0, 1.0, 1.0, mode)
         g.loadComplete()
