@@ -5,10 +5,14 @@
  */
 #include "nalu_oracle.h"
 
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP /* only the multi-core CPU-baseline build (liboracle_omp.so) */
+#include <omp.h>
+#endif
 
 /* ================================================================== mesh */
 
@@ -553,9 +557,11 @@ static void shell_sort_keys_and_values(int *keys, int *vals, int n)
     }
 }
 
-/* src/TpetraLinearSystem.C:1454-1507 */
-void orc_sum_into(orc_linsys *ls, int n_obj, const int *node_lids, const double *rhs,
-                  const double *lhs)
+/* src/TpetraLinearSystem.C:1454-1507.  [rowLo, rowHi) restricts the rows that are summed:
+ * the whole range for the reference behaviour, one thread's owned rows in the multi-core
+ * CPU-baseline build (one owner-computes partition per core, like one MPI rank per core). */
+static void sum_into_rows(orc_linsys *ls, int n_obj, const int *node_lids, const double *rhs,
+                          const double *lhs, int rowLo, int rowHi)
 {
   const int nd = ls->numDof;
   const int numRows = n_obj * nd;
@@ -577,6 +583,7 @@ void orc_sum_into(orc_linsys *ls, int n_obj, const int *node_lids, const double 
     const int cur = perm[r];
     const double *cur_lhs = lhs + (size_t)cur * numRows;
     const double cur_rhs = rhs[cur];
+    if (rowLid < rowLo || rowLid >= rowHi) continue;
     if (rowLid < ls->maxOwnedRowId) {
       const orc_graph *g = ls->ownedGraph;
       const size_t b = g->rowPointers[rowLid];
@@ -593,6 +600,12 @@ void orc_sum_into(orc_linsys *ls, int n_obj, const int *node_lids, const double 
     }
   }
   if (numRows > 64) { free(ids); free(perm); }
+}
+
+void orc_sum_into(orc_linsys *ls, int n_obj, const int *node_lids, const double *rhs,
+                  const double *lhs)
+{
+  sum_into_rows(ls, n_obj, node_lids, rhs, lhs, 0, INT_MAX);
 }
 
 /* src/TpetraLinearSystem.C:1546-1583 */
@@ -717,12 +730,31 @@ void orc_assemble_continuity_edges(orc_linsys *ls, int64_t nedges, const int *ed
                                    double gamma1, double nocFac, double interpTogether)
 {
   const double projTimeScale = dt / gamma1;
+#ifdef _OPENMP
+  /* CPU-baseline build only (-fopenmp): every thread owns a contiguous block of rows and
+   * assembles the edges that touch it, summing only its own rows. */
+#pragma omp parallel
+  {
+    const int nt = omp_get_num_threads(), t = omp_get_thread_num();
+    const int nrows = ls->maxOwnedRowId;
+    const int lo = (int)((int64_t)nrows * t / nt), hi = (int)((int64_t)nrows * (t + 1) / nt);
+    double lhs[4], rhs[2];
+    for (int64_t k = 0; k < nedges; ++k) {
+      const int L = edge_nodes[2 * k], R = edge_nodes[2 * k + 1];
+      if ((L < lo || L >= hi) && (R < lo || R >= hi)) continue;
+      continuity_edge(edge_nodes + 2 * k, edge_area + 3 * k, xyz, dpdx, vel, pressure, density,
+                      projTimeScale, nocFac, interpTogether, lhs, rhs, NULL);
+      sum_into_rows(ls, 2, edge_nodes + 2 * k, rhs, lhs, lo, hi);
+    }
+  }
+#else
   double lhs[4], rhs[2];
   for (int64_t k = 0; k < nedges; ++k) {
     continuity_edge(edge_nodes + 2 * k, edge_area + 3 * k, xyz, dpdx, vel, pressure, density,
                     projTimeScale, nocFac, interpTogether, lhs, rhs, NULL);
     orc_sum_into(ls, 2, edge_nodes + 2 * k, rhs, lhs); /* apply_coeff, :205 */
   }
+#endif
 }
 
 void orc_continuity_edge_coeffs(int64_t nedges, const int *edge_nodes,
@@ -905,6 +937,7 @@ void orc_assemble_scalar_mass_be(orc_linsys *ls, int64_t nnodes, const double *q
 void orc_spmv(const orc_linsys *ls, const double *x, double *y)
 {
   const orc_graph *g = ls->ownedGraph;
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < g->nrows; ++i) {
     double s = 0.0;
     for (size_t k = g->rowPointers[i]; k < g->rowPointers[i + 1]; ++k)
@@ -916,6 +949,7 @@ void orc_spmv(const orc_linsys *ls, const double *x, double *y)
 double orc_norm2(const double *v, int64_t n)
 {
   double s = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : s)
   for (int64_t i = 0; i < n; ++i) s += v[i] * v[i];
   return sqrt(s);
 }
@@ -923,6 +957,7 @@ double orc_norm2(const double *v, int64_t n)
 static double dot(const double *a, const double *b, int64_t n)
 {
   double s = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : s)
   for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
   return s;
 }
@@ -938,6 +973,7 @@ static void apply_precond(const orc_linsys *ls, int precond, const double *dinv,
   if (precond == 0) {
     memcpy(z, r, sizeof(double) * (size_t)n);
   } else if (precond == 1) {
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) z[i] = dinv[i] * r[i];
   } else {
     for (int64_t i = 0; i < n; ++i) { /* forward sweep */
@@ -972,6 +1008,7 @@ int orc_solve(orc_linsys *ls, const orc_solver_config *cfg, double *finalResidNr
 
   /* preconditioner_->compute() (:205): diagonal extraction */
   double *dinv = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
     double d = 0.0;
     for (size_t k = g->rowPointers[i]; k < g->rowPointers[i + 1]; ++k)
@@ -1000,7 +1037,9 @@ int orc_solve(orc_linsys *ls, const orc_solver_config *cfg, double *finalResidNr
       orc_spmv(ls, p, q);
       const double pAp = dot(p, q, n);
       const double alpha = rz / pAp;
+#pragma omp parallel for schedule(static)
       for (int64_t i = 0; i < n; ++i) x[i] += alpha * p[i];
+#pragma omp parallel for schedule(static)
       for (int64_t i = 0; i < n; ++i) r[i] -= alpha * q[i];
       ++iters;
       const double rel = orc_norm2(r, n) / r0;
@@ -1010,6 +1049,7 @@ int orc_solve(orc_linsys *ls, const orc_solver_config *cfg, double *finalResidNr
       const double rz_new = dot(r, z, n);
       const double beta = rz_new / rz;
       rz = rz_new;
+#pragma omp parallel for schedule(static)
       for (int64_t i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
     }
     free(r); free(z); free(p); free(q);

@@ -12,15 +12,20 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+# flavours: False = the checker (-O2), True = -O3 -march=native (1-core CPU baseline),
+# "omp" = the same with OpenMP (multi-core CPU baseline; never the checker)
+_NAMES = {False: "liboracle.so", True: "liboracle_fast.so", "omp": "liboracle_omp.so"}
+
+
 def build(fast=False):
     """Compile the oracle with gcc (make).  Building the checker is not using it."""
-    target = "liboracle_fast.so" if fast else "liboracle.so"
+    target = _NAMES[fast]
     subprocess.check_call(["make", "-s", "-C", _HERE, target])
     return os.path.join(_HERE, target)
 
 
 def _load(fast=False):
-    name = "liboracle_fast.so" if fast else "liboracle.so"
+    name = _NAMES[fast]
     path = os.path.join(_HERE, name)
     if not os.path.exists(path):
         build(fast)
