@@ -199,6 +199,20 @@ int nalu_gpu_nodal_grad_edges(nalu_gpu_linsys *h, nalu_gpu_vec3 edge_area_dev,
                               const double *dual_volume_dev, const double *q_dev,
                               double *gx_dev, double *gy_dev, double *gz_dev);
 
+/* ---- nodal updates of the pressure-projection loop --------------
+ * field_axpby (src/FieldFunctions.C:24-58): y = alpha x + beta y over n doubles; the
+ * pressure update p += dp of src/LowMachEquationSystem.C:676-683 is (1, pTmp, 1, pressure). */
+int nalu_gpu_field_axpby(nalu_gpu_linsys *h, int64_t n, double alpha, const double *x_dev,
+                         double beta, double *y_dev);
+/* LowMachEquationSystem::project_nodal_velocity (src/LowMachEquationSystem.C:772-855):
+ * u -= (dt/gamma1)/rho (dpdx_new - dpdx_old) on n nodes; projected_dev (one byte per node,
+ * 0 = the node is in notProjectedPart_, :826-828) may be NULL = project every node. */
+int nalu_gpu_project_nodal_velocity(nalu_gpu_linsys *h, int64_t n, double dt, double gamma1,
+                                    nalu_gpu_vec3 dpdx_new_dev, nalu_gpu_vec3 dpdx_old_dev,
+                                    const double *density_dev,
+                                    const unsigned char *projected_dev,
+                                    nalu_gpu_vec3 velocity_dev);
+
 /* ---- multi-GPU plumbing (Tpetra Import/Export + all-reduce equivalents) ----------------
  * The library packs/unpacks and reduces on the device; moving bytes between GPUs is the
  * host's job (RCCL through torch.distributed, or ncclSend/Recv from a C++ host).

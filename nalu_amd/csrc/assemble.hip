@@ -418,6 +418,29 @@ __global__ __launch_bounds__(SELL_C) void k_mass_be(SellView A, const double *__
   rhs[row] += (0.0 - res);
 }
 
+// src/FieldFunctions.C:24-58
+__global__ __launch_bounds__(256) void k_axpby(long long n, double alpha, const double *__restrict__ x,
+                                                double beta, double *__restrict__ y)
+{
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = alpha * x[i] + beta * y[i];
+}
+
+// src/LowMachEquationSystem.C:842-853
+__global__ __launch_bounds__(256) void k_project_velocity(long long n, double projTimeScale,
+                                                           nalu_gpu_vec3 gNew, nalu_gpu_vec3 gOld,
+                                                           const double *__restrict__ rho,
+                                                           const unsigned char *__restrict__ projected,
+                                                           nalu_gpu_vec3 u)
+{
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || (projected && !projected[i])) return;
+  const double fac = projTimeScale / rho[i];
+  const_cast<double *>(u.x)[i] -= fac * (gNew.x[i] - gOld.x[i]);
+  const_cast<double *>(u.y)[i] -= fac * (gNew.y[i] - gOld.y[i]);
+  const_cast<double *>(u.z)[i] -= fac * (gNew.z[i] - gOld.z[i]);
+}
+
 }  // namespace
 
 #define NG_FINALIZED(h)                                         \
@@ -501,6 +524,35 @@ extern "C" int nalu_gpu_nodal_grad_edges(nalu_gpu_linsys *h, nalu_gpu_vec3 area,
   NG_REQUIRE(vec3_ok(area) && vol && q && gx && gy && gz, NALU_GPU_EINVAL, "nodal grad: null pointer");
   if (h->nSlices)
     k_nodal_grad<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), area, vol, q, gx, gy, gz);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_field_axpby(nalu_gpu_linsys *h, int64_t n, double alpha, const double *x,
+                                    double beta, double *y)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  NG_REQUIRE(n >= 0 && (n == 0 || (x && y)), NALU_GPU_EINVAL, "field_axpby: bad arguments");
+  NG_HIP(hipSetDevice(h->device));
+  if (n) k_axpby<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(n, alpha, x, beta, y);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_project_nodal_velocity(nalu_gpu_linsys *h, int64_t n, double dt,
+                                               double gamma1, nalu_gpu_vec3 dpdx_new,
+                                               nalu_gpu_vec3 dpdx_old, const double *density,
+                                               const unsigned char *projected,
+                                               nalu_gpu_vec3 velocity)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  NG_REQUIRE(n >= 0 && gamma1 != 0.0, NALU_GPU_EINVAL, "project_nodal_velocity: bad arguments");
+  NG_REQUIRE(n == 0 || (vec3_ok(dpdx_new) && vec3_ok(dpdx_old) && density && vec3_ok(velocity)),
+             NALU_GPU_EINVAL, "project_nodal_velocity: null device pointer");
+  NG_HIP(hipSetDevice(h->device));
+  if (n)
+    k_project_velocity<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(
+        n, dt / gamma1, dpdx_new, dpdx_old, density, projected, velocity);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
 }

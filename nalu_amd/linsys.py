@@ -81,6 +81,7 @@ class GpuLinearSystem:
         self.firstNonLinearResidual = None
         self.timer_precond = 0.0
         self.history = np.zeros(0)
+        self.writeCounter = 0  # include/LinearSystem.h: writeCounter_, bumped by the caller
 
     def close(self):
         if self.h:
@@ -104,6 +105,7 @@ class GpuLinearSystem:
             self.h, n_owned, n_shared, n_ghost, gids.ctypes.data,
             None if own is None else own.ctypes.data, my_rank))
         self.n_owned, self.n_shared, self.n_ghost, self.n_cols = n_owned, n_shared, n_ghost, n
+        self.gids, self.my_rank = gids.copy(), my_rank
 
     def buildNodeGraph(self, node_lids):
         a = _np(node_lids, np.int32)
@@ -163,6 +165,32 @@ class GpuLinearSystem:
         x = np.zeros(max(self.n_rows, 1))
         L.check(self.lib.nalu_gpu_get_solution(self.h, x.ctypes.data))
         return x[:self.n_rows]
+
+    # ---- MatrixMarket dumps (src/TpetraLinearSystem.C:1901-1924, 2002-2019) -----
+    def writeToFile(self, base_filename, useOwned=True, eq_sys_name="", n_ranks=1,
+                    n_global=None):
+        """`<base>-O-<count>.mm.<p_size>` + `.rhs.<p_size>` of the owned matrix/rhs in global
+        ids.  The shared-not-owned matrix does not exist here (its rows are assembled by
+        their owner), so useOwned=False raises."""
+        if not useOwned:
+            raise RuntimeError("writeToFile: there is no shared-not-owned matrix in this "
+                               "linear system (cut edges are assembled by the row owner)")
+        from . import mmio
+        rp, ci = self.graph()
+        ng = int(n_global if n_global is not None else
+                 (self.n_owned if n_ranks == 1 else self.gids.max()))
+        names = mmio.file_names(base_filename, self.writeCounter, n_ranks, self.my_rank)
+        mmio.write_sparse(names["mm"], ng * self.num_dof, ng * self.num_dof,
+                          self.gids[:self.n_owned], rp, self.gids[ci], self.matrix_values(),
+                          eq_sys_name, "Tpetra matrix for: " + eq_sys_name)
+        mmio.write_dense(names["rhs"], self.rhs())
+        return names
+
+    def writeSolutionToFile(self, base_filename, useOwned=True, n_ranks=1):
+        from . import mmio
+        names = mmio.file_names(base_filename, self.writeCounter, n_ranks, self.my_rank)
+        mmio.write_dense(names["sln"], self.solution())
+        return names
 
     # ---- assembly -------------------------------------------------------------
     def zeroSystem(self):
@@ -287,6 +315,23 @@ class GpuLinearSystem:
                                                    _ptr(q), g.x, g.y, g.z))
 
     # ---- multi-GPU --------------------------------------------------------------
+    def field_axpby(self, alpha, x, beta, y):
+        """y = alpha x + beta y (src/FieldFunctions.C:24-58)"""
+        assert x.numel() == y.numel() and x.is_contiguous() and y.is_contiguous()
+        L.check(self.lib.nalu_gpu_field_axpby(self.h, y.numel(), alpha, _ptr(x), beta, _ptr(y)))
+
+    def project_nodal_velocity(self, dt, gamma1, dpdx_new, dpdx_old, density, velocity,
+                               projected=None):
+        """u -= (dt/gamma1)/rho (dpdx_new - dpdx_old), SoA (3, n) fields
+        (src/LowMachEquationSystem.C:772-855); `projected`: uint8 mask or None."""
+        n = density.numel()
+        for t in (dpdx_new, dpdx_old, velocity):
+            assert t.shape[0] == 3 and t.shape[-1] >= n and t.is_contiguous()
+        assert projected is None or (projected.numel() >= n and projected.element_size() == 1)
+        L.check(self.lib.nalu_gpu_project_nodal_velocity(
+            self.h, n, dt, gamma1, _vec3(dpdx_new), _vec3(dpdx_old), _ptr(density),
+            _ptr(projected), _vec3(velocity)))
+
     def set_halo_plan(self, neighbor_ranks, send_offsets, send_lids, recv_offsets):
         nb = _np(neighbor_ranks, np.int32)
         so, sl, ro = _np(send_offsets, np.int32), _np(send_lids, np.int32), _np(recv_offsets, np.int32)

@@ -932,6 +932,30 @@ void orc_assemble_scalar_mass_be(orc_linsys *ls, int64_t nnodes, const double *q
   }
 }
 
+/* src/FieldFunctions.C:24-58: y = alpha x + beta y */
+void orc_field_axpby(int64_t n, double alpha, const double *x, double beta, double *y)
+{
+  for (int64_t k = 0; k < n; ++k) y[k] = alpha * x[k] + beta * y[k];
+}
+
+/* src/LowMachEquationSystem.C:842-853: u^{n+1} -= (dt/gamma1)/rho (Gp_new - Gp_old), AoS
+ * [nnodes][3] like the STK fields; projected == NULL projects every node */
+void orc_project_nodal_velocity(int64_t nnodes, double dt, double gamma1, const double *dpdx_new,
+                                const double *dpdx_old, const double *density,
+                                const unsigned char *projected, double *velocity)
+{
+  const double projTimeScale = dt / gamma1;
+  for (int64_t k = 0; k < nnodes; ++k) {
+    if (projected && !projected[k]) continue;
+    const double fac = projTimeScale / density[k];
+    const size_t offSet = (size_t)k * 3;
+    for (int j = 0; j < 3; ++j) {
+      const double gdpx = dpdx_new[offSet + j] - dpdx_old[offSet + j];
+      velocity[offSet + j] -= fac * gdpx;
+    }
+  }
+}
+
 /* =============================================================== solver */
 
 void orc_spmv(const orc_linsys *ls, const double *x, double *y)

@@ -163,6 +163,13 @@ void orc_assemble_scalar_mass_be(orc_linsys *ls, int64_t nnodes, const double *q
                                  const double *qNp1, const double *rhoN,
                                  const double *rhoNp1, const double *dualVolume, double dt);
 
+/* src/FieldFunctions.C:24-58 */
+void orc_field_axpby(int64_t n, double alpha, const double *x, double beta, double *y);
+/* src/LowMachEquationSystem.C:772-855 (the projection loop :842-853) */
+void orc_project_nodal_velocity(int64_t nnodes, double dt, double gamma1, const double *dpdx_new,
+                                const double *dpdx_old, const double *density,
+                                const unsigned char *projected, double *velocity);
+
 /* -------------------------------------------------------------- solver */
 /* y = A x on the owned CSR (Tpetra CrsMatrix::apply call site src/LinearSolver.C:164) */
 void orc_spmv(const orc_linsys *ls, const double *x, double *y);

@@ -112,6 +112,9 @@ def _bind(lib):
     lib.orc_scalar_edge_coeffs.argtypes = scal + [_dp, _dp]
     lib.orc_nodal_grad_edges.argtypes = [C.c_int64, _ip, _dp, _dp, _dp, _dp]
     lib.orc_assemble_scalar_mass_be.argtypes = [C.POINTER(_LinSys), C.c_int64, _dp, _dp, _dp, _dp, _dp, C.c_double]
+    lib.orc_field_axpby.argtypes = [C.c_int64, C.c_double, _dp, C.c_double, _dp]
+    lib.orc_project_nodal_velocity.argtypes = [C.c_int64, C.c_double, C.c_double, _dp, _dp, _dp,
+                                               C.c_void_p, _dp]
     lib.orc_spmv.argtypes = [C.POINTER(_LinSys), _dp, _dp]
     lib.orc_solve.argtypes = [C.POINTER(_LinSys), C.POINTER(SolverConfig), C.POINTER(C.c_double),
                               _dp, C.c_int, C.POINTER(C.c_int)]
@@ -322,6 +325,21 @@ def nodal_grad(edge_nodes, area, vol, q, fast=False):
     lib(fast).orc_nodal_grad_edges(edge_nodes.shape[0], edge_nodes, f64(area), f64(vol), f64(q),
                                    dqdx)
     return dqdx
+
+
+def field_axpby(alpha, x, beta, y):
+    y = f64(y).copy()
+    lib().orc_field_axpby(y.size, alpha, f64(x), beta, y)
+    return y
+
+
+def project_nodal_velocity(dt, gamma1, dpdx_new, dpdx_old, rho, vel, projected=None):
+    """AoS (n, 3) fields; returns the projected velocity"""
+    u = f64(vel).copy()
+    m = None if projected is None else np.ascontiguousarray(projected, dtype=np.uint8)
+    lib().orc_project_nodal_velocity(len(rho), dt, gamma1, f64(dpdx_new), f64(dpdx_old), f64(rho),
+                                     None if m is None else m.ctypes.data, u)
+    return u
 
 
 # --------------------------------------------- reference F77 kernels (_ref)

@@ -318,3 +318,53 @@ def test_full_size_properties(G, torch, oracle):
     g.sumInto([0], [0.0 - p[0]], [1.0])
     g.solve(G.LinearSolverConfig(method="cg", preconditioner="jacobi", tolerance=1e-5, max_iterations=50))
     assert g.linearSolveIterations == 50 and g.history[-1] < 0.5
+
+
+def test_matrix_market_dump(G, torch, oracle, tmp_path):
+    """writeToFile / writeSolutionToFile (src/TpetraLinearSystem.C:1901-1924, 2002-2019): the
+    dumped system read back with scipy equals the oracle's, in global ids."""
+    import scipy.io
+    c = Case(oracle, 6, 0.125)
+    d = c.dev(torch)
+    ls = c.oracle_continuity()
+    g = c.gpu_system(G.GpuLinearSystem)
+    g.assemble_continuity_edges(d["coords"], d["dpdx"], d["vel"], d["p"], d["rho"], d["area"], c.dt)
+    _pin(ls, g, c)
+    g.loadComplete()
+    g.solve(G.LinearSolverConfig(method="cg", preconditioner="jacobi", tolerance=1e-8,
+                                 max_iterations=200))
+    g.writeCounter = 3
+    names = g.writeToFile(str(tmp_path / "ContinuityEQS"), eq_sys_name="ContinuityEQS")
+    names.update(g.writeSolutionToFile(str(tmp_path / "ContinuityEQS")))
+    assert names["mm"].endswith("ContinuityEQS-O-3.mm.1")
+    rp, ci, v = ls.owned_csr()
+    assert np.array_equal(scipy.io.mmread(names["mm"]).toarray(), dense(rp, ci, v, c.m.nnodes))
+    assert np.array_equal(scipy.io.mmread(names["rhs"]).ravel(), ls.owned_rhs())
+    assert np.array_equal(scipy.io.mmread(names["sln"]).ravel(), g.solution())
+    with pytest.raises(RuntimeError):
+        g.writeToFile(str(tmp_path / "x"), useOwned=False)
+
+
+def test_nodal_updates_of_the_projection_loop(G, torch, oracle):
+    """field_axpby (src/FieldFunctions.C:24-58) and project_nodal_velocity
+    (src/LowMachEquationSystem.C:772-855) against the oracle: bit-exact."""
+    rs = np.random.RandomState(11)
+    n = 1000
+    g = G.GpuLinearSystem()
+    x, y = rs.uniform(-1, 1, n), rs.uniform(-1, 1, n)
+    yd = torch.as_tensor(y, device="cuda:0")
+    g.field_axpby(1.0, torch.as_tensor(x, device="cuda:0"), 1.0, yd)  # p += dp
+    g.field_axpby(0.25, torch.as_tensor(x, device="cuda:0"), -1.5, yd)
+    g.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), oracle.field_axpby(0.25, x, -1.5, oracle.field_axpby(1.0, x, 1.0, y)))
+    gn, go, u = rs.uniform(-1, 1, (n, 3)), rs.uniform(-1, 1, (n, 3)), rs.uniform(-1, 1, (n, 3))
+    rho = rs.uniform(0.5, 2.0, n)
+    mask = (rs.uniform(size=n) > 0.2).astype(np.uint8)
+    soa = lambda a: torch.as_tensor(np.ascontiguousarray(a.T), device="cuda:0")
+    for m in (None, mask):
+        ud = soa(u)
+        g.project_nodal_velocity(0.1, 1.5, soa(gn), soa(go), torch.as_tensor(rho, device="cuda:0"), ud,
+                                 None if m is None else torch.as_tensor(m, device="cuda:0"))
+        g.synchronize()
+        assert np.array_equal(ud.cpu().numpy().T, oracle.project_nodal_velocity(0.1, 1.5, gn, go, rho, u, m))
+    g.field_axpby(1.0, yd[:0], 1.0, yd[:0])  # empty input
