@@ -146,7 +146,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dTags); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
-  NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dReduce); NG_FREE(h->dScal);
+  NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   NG_FREE(h->dY); NG_FREE(h->dList); NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf);
   NG_FREE(h->dRecvBuf);
@@ -483,6 +483,32 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
   NG_HIP(hipMalloc(&h->dT, sizeof(double) * nC));
   NG_HIP(hipMalloc(&h->dPartials, sizeof(double) * PARTIAL_SLOTS * MAX_BLOCKS));
   NG_HIP(hipMalloc(&h->dSlicePartials, sizeof(double) * std::max(h->nSlices, 1)));
+
+  // slices whose rows read shared/ghost columns ("boundary") and the rest ("interior"): the
+  // SpMV of the interior slices overlaps the halo exchange (Tpetra's Import in apply)
+  h->nInterior = h->nBoundary = 0;
+  if (h->nCols > nO && h->nSlices > 0) {
+    std::vector<char> halo((size_t)h->nSlices, 0);
+    parallel_for(h->nSlices, [&](int64_t a, int64_t b) {
+      for (int64_t sl = a; sl < b; ++sl) {
+        const int r1 = std::min(nO, (int)(sl + 1) * SELL_C);
+        char any = 0;
+        for (int64_t k = h->rowPtr[sl * SELL_C]; k < h->rowPtr[r1] && !any; ++k)
+          any = h->colIdx[k] >= nO;
+        halo[sl] = any;
+      }
+    });
+    std::vector<int> lists((size_t)h->nSlices);
+    int ni = 0;
+    for (int sl = 0; sl < h->nSlices; ++sl)
+      if (!halo[sl]) lists[ni++] = sl;
+    h->nInterior = ni;
+    for (int sl = 0; sl < h->nSlices; ++sl)
+      if (halo[sl]) lists[ni++] = sl;
+    h->nBoundary = h->nSlices - h->nInterior;
+    NG_HIP(hipMalloc(&h->dSliceLists, sizeof(int) * (size_t)h->nSlices));
+    NG_HIP(hipMemcpy(h->dSliceLists, lists.data(), sizeof(int) * (size_t)h->nSlices, hipMemcpyHostToDevice));
+  }
   NG_HIP(hipMalloc(&h->dReduce, sizeof(double) * REDUCE_CAP));
   NG_HIP(hipMalloc(&h->dScal, sizeof(SolverScalars)));
   NG_HIP(hipHostMalloc(&h->hPinned, 4096, hipHostMallocDefault));

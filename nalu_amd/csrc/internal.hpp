@@ -115,6 +115,8 @@ struct nalu_gpu_linsys {
   int vCap = 0;
   double *dPartials = nullptr;  // PARTIAL_SLOTS x MAX_BLOCKS
   double *dSlicePartials = nullptr;  // nSlices: per-slice partials of the SpMV-fused dot
+  int *dSliceLists = nullptr;        // interior slices, then boundary slices (multi-rank only)
+  int nInterior = 0, nBoundary = 0;
   double *dReduce = nullptr;    // REDUCE_CAP
   nalu_gpu::SolverScalars *dScal = nullptr;
   double *dHist = nullptr;

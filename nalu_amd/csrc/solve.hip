@@ -199,10 +199,11 @@ __global__ __launch_bounds__(SELL_C) void k_spmv(SellView A, const double *__res
                                                   const double *__restrict__ dinv,
                                                   double *__restrict__ y,
                                                   double *__restrict__ partials,
-                                                  const SolverScalars *__restrict__ sc, int run)
+                                                  const SolverScalars *__restrict__ sc, int run,
+                                                  const int *__restrict__ list, int nList)
 {
   if (sc && sc->done) return;
-  const int s = xcd_run(blockIdx.x, A.nSlices, run);
+  const int s = list ? list[xcd_run(blockIdx.x, nList, run)] : xcd_run(blockIdx.x, A.nSlices, run);
   const int row = s * SELL_C + threadIdx.x;
   const double sum = row_sum<DINV>(A, A.sliceOff[s] + threadIdx.x, A.sliceWidth[s], x, dinv);
   double acc[1] = {0.0};
@@ -213,19 +214,36 @@ __global__ __launch_bounds__(SELL_C) void k_spmv(SellView A, const double *__res
   if (DOT) block_sums<1>(acc, partials, 1, s);
 }
 
-// DOT: the partials land in h->dSlicePartials[0 .. *nblocks)
+// DOT: the partials land in h->dSlicePartials[0 .. *nblocks).  list != nullptr: only the
+// nList slices of the list
 template <bool DOT, bool DINV>
-int launch_spmv(nalu_gpu_linsys *h, const double *x, double *y, bool useDone, int *nblocks)
+int launch_spmv(nalu_gpu_linsys *h, const double *x, double *y, bool useDone, int *nblocks,
+                const int *list = nullptr, int nList = 0)
 {
   if (nblocks) *nblocks = h->nSlices;
-  if (h->nSlices == 0) return NALU_GPU_OK;
+  const int nb = list ? nList : h->nSlices;
+  if (nb == 0) return NALU_GPU_OK;
   timer_begin(h, NALU_GPU_T_SPMV);
-  k_spmv<DOT, DINV><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), x, h->dDinv, y,
-                                                           h->dSlicePartials,
-                                                           useDone ? h->dScal : nullptr, h->xcdRun);
+  k_spmv<DOT, DINV><<<nb, SELL_C, 0, h->stream>>>(sell_view(h), x, h->dDinv, y, h->dSlicePartials,
+                                                   useDone ? h->dScal : nullptr, h->xcdRun, list,
+                                                   nList);
   timer_end(h, NALU_GPU_T_SPMV);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
+}
+
+// y = A x with the halo of x (Tpetra Import inside CrsMatrix::apply): pack + post the
+// exchange, multiply the slices that read owned columns only while it is in flight, then
+// finish the exchange and multiply the rest.
+template <bool DOT, bool DINV>
+int spmv_with_halo(nalu_gpu_linsys *h, double *x, double *y, bool useDone, int *nblocks)
+{
+  if (h->nCols == h->nOwned) return launch_spmv<DOT, DINV>(h, x, y, useDone, nblocks);
+  NG_TRY(halo_begin(h, x));
+  NG_TRY((launch_spmv<DOT, DINV>(h, x, y, useDone, nblocks, h->dSliceLists, h->nInterior)));
+  NG_TRY(halo_end(h, x));
+  return launch_spmv<DOT, DINV>(h, x, y, useDone, nblocks, h->dSliceLists + h->nInterior,
+                                h->nBoundary);
 }
 
 // ------------------------------------------------------------------ vector kernels
@@ -539,8 +557,7 @@ int solve_cg(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEve
   SolverScalars sc;
   for (int it = 0; it < cfg->max_iterations; ++it) {
     int sb = 0;
-    NG_TRY(halo_exchange(h, h->dP));
-    NG_TRY((launch_spmv<true, false>(h, h->dP, h->dQ, true, &sb)));
+    NG_TRY((spmv_with_halo<true, false>(h, h->dP, h->dQ, true, &sb)));
     if (h->hasComm) {
       NG_TRY(finish_reduction(h, 1, sb, h->dSlicePartials));
       k_cg_scal_a<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
@@ -597,8 +614,7 @@ int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int check
       k_gm_resid<<<vb, 256, 0, h->stream>>>(n, h->dRhs, nullptr, h->dW, h->dX, h->dPartials);
     } else {
       int sb = 0;
-      NG_TRY(halo_exchange(h, h->dX));
-      NG_TRY((launch_spmv<false, false>(h, h->dX, h->dQ, false, &sb)));
+      NG_TRY((spmv_with_halo<false, false>(h, h->dX, h->dQ, false, &sb)));
       k_gm_resid<<<vb, 256, 0, h->stream>>>(n, h->dRhs, h->dQ, h->dW, h->dX, h->dPartials);
     }
     NG_HIP(hipGetLastError());
@@ -613,8 +629,7 @@ int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int check
     for (int j = 0; j < m && enq < cfg->max_iterations; ++j, ++enq) {
       double *vj = h->dV + (size_t)j * ld;
       int sb = 0;
-      NG_TRY(halo_exchange(h, vj));
-      NG_TRY((launch_spmv<false, true>(h, vj, h->dW, true, &sb)));
+      NG_TRY((spmv_with_halo<false, true>(h, vj, h->dW, true, &sb)));
       double *Hcol = h->dH + (size_t)j * (m + 1);
       for (int pass = 0; pass < 2; ++pass) {  // ICGS: two classical Gram-Schmidt passes
         for (int i0 = 0; i0 <= j; i0 += 8) {
@@ -730,8 +745,7 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
   // residual_norm (src/LinearSolver.C:153-178) and ownedRhs_->norm2()
   // (src/TpetraLinearSystem.C:1756); x gets its shared/ghost entries (sync_field :1753)
   int sb = 0;
-  NG_TRY(halo_exchange(h, h->dX));
-  NG_TRY((launch_spmv<false, false>(h, h->dX, h->dQ, false, &sb)));
+  NG_TRY((spmv_with_halo<false, false>(h, h->dX, h->dQ, false, &sb)));
   const int vb = vec_grid(h->nOwned);
   k_resid_norms<<<vb, 256, 0, h->stream>>>(h->nOwned, h->dQ, h->dRhs, h->dPartials);
   NG_HIP(hipGetLastError());

@@ -143,7 +143,12 @@ def gpu_test(rank, world, method):
 def main():
     mode = sys.argv[1]
     import datetime
-    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=90))
+    backend = os.environ.get("NALU_TEST_BACKEND", "gloo")
+    kw = {}
+    if backend == "nccl":  # RCCL: one rank per GPU, so only world size 1 fits the test box
+        torch.cuda.set_device(0)
+        kw["device_id"] = torch.device("cuda:0")
+    dist.init_process_group(backend, timeout=datetime.timedelta(seconds=90), **kw)
     rank, world = dist.get_rank(), dist.get_world_size()
     if mode == "plan":
         plan_test(rank, world)
