@@ -199,6 +199,19 @@ int nalu_gpu_nodal_grad_edges(nalu_gpu_linsys *h, nalu_gpu_vec3 edge_area_dev,
                               const double *dual_volume_dev, const double *q_dev,
                               double *gx_dev, double *gy_dev, double *gz_dev);
 
+/* ---- Hex8 geometry preprocessing --------------------------------
+ * ComputeGeometryInteriorAlgorithm::execute (src/ComputeGeometryInteriorAlgorithm.C:78-216)
+ * for Hex8: dual_nodal_volume (n_cols) from hex_scv_det and edge_area_vector (n_edges, SoA)
+ * from hex_scs_det (src/master_element/MasterElementWork.F:1-231, 233-452) with the sign
+ * convention of :196-212 (relative to the edge's node 0).  hex_nodes_dev is [n_elem][8]
+ * local node ids in the reference's Hex8 node order.  Sums run in ascending element order:
+ * deterministic and bit-identical to the element loop.  Element edges that are not
+ * registered edges of this system are skipped; volumes of shared/ghost nodes only hold the
+ * local elements' share (the reference parallel_sum's them, :126-129). */
+int nalu_gpu_compute_geometry_hex8(nalu_gpu_linsys *h, int64_t n_elem, const int *hex_nodes_dev,
+                                   nalu_gpu_vec3 coordinates_dev, double *dual_volume_dev,
+                                   double *area_x_dev, double *area_y_dev, double *area_z_dev);
+
 /* ---- nodal updates of the pressure-projection loop --------------
  * field_axpby (src/FieldFunctions.C:24-58): y = alpha x + beta y over n doubles; the
  * pressure update p += dp of src/LowMachEquationSystem.C:676-683 is (1, pTmp, 1, pressure). */

@@ -25,7 +25,7 @@ SYMBOLS = [
     "nalu_gpu_apply_dirichlet", "nalu_gpu_reset_rows", "nalu_gpu_load_complete",
     "nalu_gpu_solve", "nalu_gpu_spmv", "nalu_gpu_dot", "nalu_gpu_axpy", "nalu_gpu_norm2",
     "nalu_gpu_compute_mdot_edges", "nalu_gpu_nodal_grad_edges",
-    "nalu_gpu_field_axpby", "nalu_gpu_project_nodal_velocity", "nalu_gpu_set_halo_plan",
+    "nalu_gpu_field_axpby", "nalu_gpu_project_nodal_velocity", "nalu_gpu_compute_geometry_hex8", "nalu_gpu_set_halo_plan",
     "nalu_gpu_set_comm", "nalu_gpu_get_comm_buffers", "nalu_gpu_halo_exchange",
     "nalu_gpu_set_profiling", "nalu_gpu_get_timer", "nalu_gpu_reset_timers",
     "nalu_gpu_synchronize",
@@ -128,6 +128,7 @@ def load():
         "nalu_gpu_norm2": [vp, vp, i64, P(dbl)],
         "nalu_gpu_compute_mdot_edges": [vp, P(ContinuityFields), dbl, dbl, dbl, dbl, vp],
         "nalu_gpu_nodal_grad_edges": [vp, Vec3, vp, vp, vp, vp, vp],
+        "nalu_gpu_compute_geometry_hex8": [vp, i64, vp, Vec3, vp, vp, vp, vp],
         "nalu_gpu_field_axpby": [vp, i64, dbl, vp, dbl, vp],
         "nalu_gpu_project_nodal_velocity": [vp, i64, dbl, dbl, Vec3, Vec3, vp, vp, Vec3],
         "nalu_gpu_set_halo_plan": [vp, ci, vp, vp, vp, vp],

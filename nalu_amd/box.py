@@ -98,6 +98,7 @@ class BoxSlab:
             # consecutive edges, so the edge-field gathers of the row kernels coalesce.
             o = np.argsort(ed, kind="stable")
             en, ed = en[o], ed[o]
+        self._lid, self._nzl = lid, nzl
         self.edge_nodes = np.ascontiguousarray(lid[en].astype(np.int32))
         self.edge_dir = ed
         self.n_edges = len(ed)
@@ -118,6 +119,18 @@ class BoxSlab:
         self.send_offsets = np.array(so, np.int32)
         self.send_lids = np.concatenate(sl) if sl else np.zeros(0, np.int32)
         self.recv_offsets = np.array(ro, np.int32)
+
+    def hex_nodes(self):
+        """(n_elem, 8) int32 local node ids of the Hex8 elements of the local box, node order
+        of the reference's generated meshes (bottom face counter-clockwise, then the top)."""
+        nxn, nyn, _ = self.dims
+        i, j, k = np.meshgrid(np.arange(nxn - 1), np.arange(nyn - 1), np.arange(self._nzl - 1),
+                              indexing="ij")
+        n0 = (i + nxn * (j + nyn * k)).transpose(2, 1, 0).reshape(-1)  # i fastest
+        sx, sy, sz = 1, nxn, nxn * nyn
+        h = np.stack([n0, n0 + sx, n0 + sx + sy, n0 + sy, n0 + sz, n0 + sx + sz,
+                      n0 + sx + sy + sz, n0 + sy + sz], axis=1)
+        return np.ascontiguousarray(self._lid[h].astype(np.int32))
 
     # uniform lattice geometry (exact for the unperturbed box)
     def spacing(self):

@@ -315,6 +315,20 @@ class GpuLinearSystem:
                                                    _ptr(q), g.x, g.y, g.z))
 
     # ---- multi-GPU --------------------------------------------------------------
+    def compute_geometry_hex8(self, hex_nodes, coords, dual_volume_out, edge_area_out):
+        """dual_nodal_volume (n_cols) and edge_area_vector (3, n_edges) of a Hex8 mesh
+        (src/ComputeGeometryInteriorAlgorithm.C:78-216); hex_nodes: int32 device tensor
+        (n_elem, 8) of local node ids."""
+        ne = getattr(self, "n_edges", 0)
+        assert hex_nodes.dtype.itemsize == 4 and hex_nodes.is_contiguous() and hex_nodes.shape[-1] == 8
+        self._check_fields(coords, dual_volume_out)
+        assert edge_area_out.shape[0] == 3 and edge_area_out.shape[-1] >= ne and edge_area_out.is_contiguous()
+        n = edge_area_out.shape[-1]
+        p = edge_area_out.data_ptr()
+        L.check(self.lib.nalu_gpu_compute_geometry_hex8(
+            self.h, hex_nodes.shape[0], _ptr(hex_nodes), _vec3(coords), _ptr(dual_volume_out),
+            C.c_void_p(p), C.c_void_p(p + 8 * n), C.c_void_p(p + 16 * n)))
+
     def field_axpby(self, alpha, x, beta, y):
         """y = alpha x + beta y (src/FieldFunctions.C:24-58)"""
         assert x.numel() == y.numel() and x.is_contiguous() and y.is_contiguous()

@@ -298,6 +298,13 @@ def test_full_size_properties(G, torch, oracle):
     g.beginLinearSystemConstruction(S.n_owned, gids=S.gids)
     g.buildEdgeToNodeGraph(S.edge_nodes)
     g.finalizeLinearSystem()
+    # Hex8 geometry on the device at full size: equals the analytic lattice geometry and the
+    # dual volumes fill the box
+    dv = torch.empty(S.n_local, dtype=torch.float64, device="cuda:0")
+    da = torch.empty(3, S.n_edges, dtype=torch.float64, device="cuda:0")
+    g.compute_geometry_hex8(torch.as_tensor(S.hex_nodes(), device="cuda:0"), coords, dv, da)
+    assert rel_err(dv.cpu().numpy(), vol) <= 1e-12 and rel_err(da.cpu().numpy(), area) <= 1e-12
+    assert abs(dv.sum().item() - 1.0) <= 1e-12
     grad = torch.zeros(3, S.n_local, dtype=torch.float64, device="cuda:0")
     g.nodal_grad_edges(ar, t(vol), pd, grad)
     res = {}
@@ -368,3 +375,30 @@ def test_nodal_updates_of_the_projection_loop(G, torch, oracle):
         g.synchronize()
         assert np.array_equal(ud.cpu().numpy().T, oracle.project_nodal_velocity(0.1, 1.5, gn, go, rho, u, m))
     g.field_axpby(1.0, yd[:0], 1.0, yd[:0])  # empty input
+
+
+@pytest.mark.parametrize("dims,perturb", [((2, 2, 2), 0.0), ((4, 3, 5), 0.125), ((9, 9, 9), 0.125)])
+def test_hex8_geometry_on_device(G, torch, oracle, dims, perturb):
+    """dual_nodal_volume / edge_area_vector (src/ComputeGeometryInteriorAlgorithm.C:78-216)
+    against the oracle, whose SCS/SCV kernels are pinned bit for bit to the reference's F77
+    (tests/test_oracle_golden.py): gathers in element order => bit-exact."""
+    c = Case(oracle, 0, perturb, dims=dims)
+    d = c.dev(torch)
+    g = c.gpu_system(G.GpuLinearSystem)
+    hexes = torch.as_tensor(np.ascontiguousarray(c.m.hex_nodes, dtype=np.int32), device="cuda:0")
+    vol = torch.full((c.m.nnodes,), -1.0, dtype=torch.float64, device="cuda:0")
+    area = torch.full((3, c.m.nedges), -1.0, dtype=torch.float64, device="cuda:0")
+    g.compute_geometry_hex8(hexes, d["coords"], vol, area)
+    g.synchronize()
+    assert np.array_equal(vol.cpu().numpy(), c.vol)
+    assert np.array_equal(area.cpu().numpy().T, c.area)
+    # conservation: the dual volumes fill the box
+    assert abs(vol.sum().item() - 1.0) < 1e-12
+    # element ids out of range are rejected, not dereferenced
+    bad = hexes.clone()
+    bad[0, 0] = c.m.nnodes
+    with pytest.raises(G.NaluGpuError):
+        g.compute_geometry_hex8(bad, d["coords"], vol, area)
+    g.compute_geometry_hex8(hexes[:0], d["coords"], vol, area)  # no elements: all zero
+    g.synchronize()
+    assert float(vol.abs().max()) == 0.0 and float(area.abs().max()) == 0.0
