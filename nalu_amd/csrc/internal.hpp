@@ -127,6 +127,11 @@ struct nalu_gpu_linsys {
   int *dList = nullptr;     // node-list staging for BC kernels
   int64_t listCap = 0;
 
+  // SGS level schedule (precond.hip)
+  bool sgsReady = false;
+  std::vector<int> sgsFwdOff, sgsBwdOff;
+  int *dSgsFwdRows = nullptr, *dSgsBwdRows = nullptr;
+
   // halo
   int nNbr = 0;
   std::vector<int> nbrRanks, sendOff, recvOff;
@@ -212,5 +217,7 @@ int halo_end(nalu_gpu_linsys *h, double *vec);
 // in a fixed order into dReduce[0..nslots) and (if a comm is set) all-reduces them.
 int finish_reduction(nalu_gpu_linsys *h, int nslots, int nblocks, const double *src = nullptr);
 int vec_grid(int64_t n);
+int ensure_sgs_levels(nalu_gpu_linsys *h);
+int apply_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone);
 
 }  // namespace nalu_gpu

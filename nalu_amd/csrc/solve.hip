@@ -583,8 +583,131 @@ int solve_cg(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEve
   return NALU_GPU_OK;
 }
 
+// ---- CG with a preconditioner that is not a diagonal scaling (SGS): z is a vector of its
+// own, the residual test comes before the preconditioner application as in the oracle
+__global__ __launch_bounds__(256) void k_pcg_init(long long n, const double *__restrict__ b,
+                                                   double *__restrict__ x, double *__restrict__ r,
+                                                   double *__restrict__ partials)
+{
+  double acc[1] = {0.0};
+  GRID_STRIDE(i, n) {
+    const double ri = b[i];
+    x[i] = 0.0;
+    r[i] = ri;
+    acc[0] += ri * ri;
+  }
+  block_sums<1>(acc, partials, 1);
+}
+
+__global__ __launch_bounds__(256) void k_dot_done(long long n, const SolverScalars *__restrict__ sc,
+                                                   const double *__restrict__ a,
+                                                   const double *__restrict__ b,
+                                                   double *__restrict__ partials)
+{
+  if (sc->done) return;
+  double acc[1] = {0.0};
+  GRID_STRIDE(i, n) acc[0] += a[i] * b[i];
+  block_sums<1>(acc, partials, 1);
+}
+
+__global__ __launch_bounds__(256) void k_pcg_update(long long n, const SolverScalars *__restrict__ sc,
+                                                     const double *__restrict__ p,
+                                                     const double *__restrict__ q,
+                                                     double *__restrict__ x, double *__restrict__ r,
+                                                     double *__restrict__ partials)
+{
+  if (sc->done) return;
+  const double alpha = sc->alpha;
+  double acc[1] = {0.0};
+  GRID_STRIDE(i, n) {
+    x[i] += alpha * p[i];
+    const double ri = r[i] - alpha * q[i];
+    r[i] = ri;
+    acc[0] += ri * ri;
+  }
+  block_sums<1>(acc, partials, 1);
+}
+
+__global__ void k_pcg_scal_test(SolverScalars *sc, const double *red, double *hist)
+{
+  if (sc->done) return;
+  sc->iter += 1;
+  const double rel = sqrt(red[0]) / sc->r0norm;
+  if (sc->iter < sc->histCap) hist[sc->iter] = rel;
+  if (rel <= sc->tol || sc->iter >= sc->maxIter) sc->done = 1;
+}
+
+__global__ void k_pcg_scal_beta(SolverScalars *sc, const double *red)
+{
+  if (sc->done) return;
+  sc->beta = red[0] / sc->rz;
+  sc->rz = red[0];
+}
+
+__global__ __launch_bounds__(256) void k_pcg_p(long long n, const SolverScalars *__restrict__ sc,
+                                                const double *__restrict__ z, double *__restrict__ p,
+                                                int first)
+{
+  if (sc->done) return;
+  const double beta = sc->beta;
+  GRID_STRIDE(i, n) p[i] = first ? z[i] : z[i] + beta * p[i];
+}
+
+int solve_cg_sgs(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEvery)
+{
+  const long long n = h->nOwned;
+  const int vb = vec_grid(n);
+  double *z = h->dW;
+  k_pcg_init<<<vb, 256, 0, h->stream>>>(n, h->dRhs, h->dX, h->dR, h->dPartials);
+  NG_TRY(reduce_partials(h, 1, vb, 1));  // r.r -> reduce[1]
+  NG_TRY(apply_sgs(h, h->dR, z, false));
+  k_dot<<<vb, 256, 0, h->stream>>>(n, h->dR, z, h->dPartials);
+  NG_TRY(reduce_partials(h, 1, vb, 0));  // r.z -> reduce[0]
+  NG_TRY(allreduce(h, 2));
+  k_cg_scal_init<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist, cfg->tolerance,
+                                         cfg->max_iterations, h->histCap);
+  k_pcg_p<<<vb, 256, 0, h->stream>>>(n, h->dScal, z, h->dP, 1);
+  NG_HIP(hipGetLastError());
+  SolverScalars sc;
+  for (int it = 0; it < cfg->max_iterations; ++it) {
+    int sb = 0;
+    NG_TRY((spmv_with_halo<true, false>(h, h->dP, h->dQ, true, &sb)));
+    NG_TRY(finish_reduction(h, 1, sb, h->dSlicePartials));
+    k_cg_scal_a<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
+    k_pcg_update<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dP, h->dQ, h->dX, h->dR, h->dPartials);
+    NG_TRY(finish_reduction(h, 1, vb));
+    k_pcg_scal_test<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist);
+    NG_TRY(apply_sgs(h, h->dR, z, true));
+    k_dot_done<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dR, z, h->dPartials);
+    NG_TRY(finish_reduction(h, 1, vb));
+    k_pcg_scal_beta<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
+    k_pcg_p<<<vb, 256, 0, h->stream>>>(n, h->dScal, z, h->dP, 0);
+    NG_HIP(hipGetLastError());
+    if ((it + 1) % checkEvery == 0 && it + 1 < cfg->max_iterations) {
+      NG_TRY(read_scalars(h, &sc));
+      if (sc.done) break;
+    }
+  }
+  return NALU_GPU_OK;
+}
+
+// s = sum_i y_i V_i (GMRES update with a non-diagonal right preconditioner)
+__global__ __launch_bounds__(256) void k_gm_combine(long long n, const SolverScalars *__restrict__ sc,
+                                                     const double *__restrict__ V, long long ld,
+                                                     const double *__restrict__ y,
+                                                     double *__restrict__ out)
+{
+  const int jn = sc->j;
+  GRID_STRIDE(i, n) {
+    double s = 0.0;
+    for (int t = 0; t < jn; ++t) s += y[t] * V[(long long)t * ld + i];
+    out[i] = s;
+  }
+}
+
 int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEvery)
 {
+  const bool sgs = cfg->precond == NALU_GPU_PRECOND_SGS;
   const long long n = h->nOwned, ld = h->nCols;
   const int m = cfg->kspace;
   NG_REQUIRE(m >= 1 && m + 1 <= REDUCE_CAP, NALU_GPU_EINVAL, "kspace must be in [1,%d]", REDUCE_CAP - 1);
@@ -629,7 +752,12 @@ int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int check
     for (int j = 0; j < m && enq < cfg->max_iterations; ++j, ++enq) {
       double *vj = h->dV + (size_t)j * ld;
       int sb = 0;
-      NG_TRY((spmv_with_halo<false, true>(h, vj, h->dW, true, &sb)));
+      if (sgs) {  // w = A (M^-1 v_j)
+        NG_TRY(apply_sgs(h, vj, h->dP, true));
+        NG_TRY((spmv_with_halo<false, false>(h, h->dP, h->dW, true, &sb)));
+      } else {
+        NG_TRY((spmv_with_halo<false, true>(h, vj, h->dW, true, &sb)));
+      }
       double *Hcol = h->dH + (size_t)j * (m + 1);
       for (int pass = 0; pass < 2; ++pass) {  // ICGS: two classical Gram-Schmidt passes
         for (int i0 = 0; i0 <= j; i0 += 8) {
@@ -653,7 +781,13 @@ int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int check
       }
     }
     k_gm_solve_y<<<1, 1, 0, h->stream>>>(h->dScal, h->dH, h->dG, h->dY, m);
-    k_gm_update_x<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dV, ld, h->dY, h->dDinv, h->dX);
+    if (sgs) {  // x += M^-1 (V y)
+      k_gm_combine<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dV, ld, h->dY, h->dR);
+      NG_TRY(apply_sgs(h, h->dR, h->dP, false));
+      k_axpy<<<vb, 256, 0, h->stream>>>(n, 1.0, h->dP, h->dX);
+    } else {
+      k_gm_update_x<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dV, ld, h->dY, h->dDinv, h->dX);
+    }
     NG_HIP(hipGetLastError());
     NG_TRY(read_scalars(h, &sc));
     if (stop || sc.done || sc.iter >= cfg->max_iterations) break;
@@ -717,9 +851,10 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
   NG_REQUIRE(cfg && info, NALU_GPU_EINVAL, "null config/info");
   NG_REQUIRE(cfg->method == NALU_GPU_METHOD_CG || cfg->method == NALU_GPU_METHOD_GMRES,
              NALU_GPU_EUNSUPPORTED, "solver method %d (supported: cg, gmres)", cfg->method);
-  NG_REQUIRE(cfg->precond == NALU_GPU_PRECOND_NONE || cfg->precond == NALU_GPU_PRECOND_JACOBI,
+  NG_REQUIRE(cfg->precond == NALU_GPU_PRECOND_NONE || cfg->precond == NALU_GPU_PRECOND_JACOBI ||
+                 cfg->precond == NALU_GPU_PRECOND_SGS,
              NALU_GPU_EUNSUPPORTED,
-             "preconditioner %d (supported: none, jacobi; the reference throws on unknown "
+             "preconditioner %d (supported: none, jacobi, sgs; the reference throws on unknown "
              "names, src/LinearSolverConfig.C:97-99)", cfg->precond);
   NG_REQUIRE(cfg->max_iterations >= 0 && cfg->tolerance >= 0.0, NALU_GPU_EINVAL, "bad solver limits");
   NG_TRY(materialize_zero(h));
@@ -730,7 +865,8 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
   const auto t0 = std::chrono::steady_clock::now();
   timer_begin(h, NALU_GPU_T_PRECOND);
   if (h->nSlices)
-    k_extract_dinv<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), cfg->precond == NALU_GPU_PRECOND_JACOBI, h->dDinv);
+    k_extract_dinv<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), cfg->precond != NALU_GPU_PRECOND_NONE, h->dDinv);
+  if (cfg->precond == NALU_GPU_PRECOND_SGS) NG_TRY(ensure_sgs_levels(h));
   NG_HIP(hipGetLastError());
   NG_TRY(halo_exchange(h, h->dDinv));
   timer_end(h, NALU_GPU_T_PRECOND);
@@ -738,7 +874,9 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
   const auto t1 = std::chrono::steady_clock::now();
 
   timer_begin(h, NALU_GPU_T_SOLVE);
-  if (cfg->method == NALU_GPU_METHOD_CG) NG_TRY(solve_cg(h, cfg, checkEvery));
+  if (cfg->method == NALU_GPU_METHOD_CG && cfg->precond == NALU_GPU_PRECOND_SGS)
+    NG_TRY(solve_cg_sgs(h, cfg, checkEvery));
+  else if (cfg->method == NALU_GPU_METHOD_CG) NG_TRY(solve_cg(h, cfg, checkEvery));
   else NG_TRY(solve_gmres(h, cfg, checkEvery));
   timer_end(h, NALU_GPU_T_SOLVE);
 

@@ -127,6 +127,12 @@ def gpu_test(rank, world, method):
         assert np.abs(gv[grp[r]:grp[r + 1]][o] - ref).max() <= 1e-12 * np.abs(ref).max()
     assert rel_err(gb, ls.owned_rhs()[gi[:S.n_owned]]) <= 1e-12
     kw = dict(tolerance=1e-9, max_iterations=200, kspace=30)
+    if world == 1:
+        # SGS is processor-local (Ifpack2): only at np = 1 does it equal the oracle's sweep
+        ref = ls.solve(method, "sgs", **kw)
+        g.solve(nalu_amd.LinearSolverConfig(method=method, preconditioner="sgs", **kw))
+        assert g.linearSolveIterations == ref["iters"]
+        assert np.abs(g.history - ref["history"]).max() <= 1e-10
     ref = ls.solve(method, "jacobi", **kw)
     x = torch.zeros(S.n_local, dtype=torch.float64, device=dev)
     g.solve(nalu_amd.LinearSolverConfig(method=method, preconditioner="jacobi", **kw), x)
