@@ -5,3 +5,4 @@ the Python-side mirror of the reference's LinearSystem interface used by tests a
 from ._lib import LIB_PATH, NaluGpuError, load  # noqa: F401
 from .box import BoxSlab, box_edges, split_elems  # noqa: F401
 from .linsys import GpuLinearSystem, LinearSolverConfig  # noqa: F401
+from . import eqsys  # noqa: F401

@@ -407,3 +407,41 @@ def test_hex8_geometry_on_device(G, torch, oracle, dims, perturb):
     g.compute_geometry_hex8(hexes[:0], d["coords"], vol, area)  # no elements: all zero
     g.synchronize()
     assert float(vol.abs().max()) == 0.0 and float(area.abs().max()) == 0.0
+
+
+def test_equation_system_driver(G, torch, oracle, tmp_path):
+    """EquationSystem::assemble_and_solve / SolverAlgorithmDriver::execute mirror
+    (src/EquationSystem.C:263-307, src/SolverAlgorithmDriver.C:109-138): algorithms run in
+    AlgorithmType order (INTERIOR < MASS < REF_PRESSURE), Dirichlet last; same system and
+    solution as the hand-sequenced calls / the oracle."""
+    from nalu_amd import eqsys
+    c = Case(oracle, 8, 0.125)
+    d = c.dev(torch)
+    g = G.GpuLinearSystem()
+    g.beginLinearSystemConstruction(c.m.nnodes)
+    cfg = G.LinearSolverConfig(method="gmres", preconditioner="sgs", tolerance=1e-10,
+                               max_iterations=100, kspace=30, write_matrix_files=True)
+    eq = eqsys.EquationSystem(g, cfg, str(tmp_path / "ContinuityEQS"), sync=g.synchronize)
+    # registered out of order on purpose
+    eq.solverAlgDriver.solverAlgMap["REF_PRESSURE"] = eqsys.FixPressureAtNodeAlgorithm(0, 0.0, c.p[0])
+    eq.solverAlgDriver.solverAlgMap["INTERIOR"] = eqsys.AssembleContinuityEdgeSolverAlgorithm(
+        c.m.edge_nodes, d, c.dt)
+    bc_nodes = np.array([c.m.nnodes - 1], np.int32)
+    bcv = torch.full((c.m.nnodes,), 0.25, dtype=torch.float64, device="cuda:0")
+    eq.solverAlgDriver.solverDirichAlgMap["WALL"] = eqsys.DirichletBC(bc_nodes, d["p"], bcv)
+    eq.initialize()
+    ls = c.oracle_continuity()
+    ls.reset_rows([0])
+    ls.sum_into([0], [0.0 - c.p[0]], [1.0])
+    ls.apply_dirichlet(bc_nodes, c.p, 0.25 * np.ones(c.m.nnodes))
+    for rep in range(2):  # a second Picard-style pass reuses everything
+        x = torch.zeros(c.m.nnodes, dtype=torch.float64, device="cuda:0")
+        assert eq.assemble_and_solve(x) == 0
+        _compare_system(g, ls, exact=True)
+    ref = ls.solve("gmres", "sgs", tolerance=1e-10, max_iterations=100, kspace=30)
+    assert g.linearSolveIterations == ref["iters"]
+    assert rel_err(x.cpu().numpy(), ref["x"]) <= TOL_SOLVE
+    assert eq.numberLinearIterations == 2 * ref["iters"]
+    assert eq.timerAssemble > 0 and eq.timerSolve > 0 and eq.timerLoadComplete >= 0
+    import os
+    assert os.path.exists(str(tmp_path / "ContinuityEQS-O-1.sln.1")) and g.writeCounter == 2
