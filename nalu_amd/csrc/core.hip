@@ -146,7 +146,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dTags); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
-  NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dReduce); NG_FREE(h->dScal);
+  NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   NG_FREE(h->dY); NG_FREE(h->dList); NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf);
   NG_FREE(h->dRecvBuf);
@@ -432,6 +432,58 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
     NG_HIP(hipStreamSynchronize(h->stream));
     (void)hipFree(dRowPtr);
     (void)hipFree(dColIdx);
+  }
+
+  // Column-offset compression for SpMV.  On meshes with any regularity in the numbering the
+  // k-th column of most rows of a slice is row + (one constant per slice and k): the stencil
+  // offset.  Store that constant (the most frequent c - row over the slice's rows) per
+  // (slice, k) and flag the rows that deviate anywhere ("exceptional": e.g. the two lattice
+  // boundary rows of an x-line, whose entries are shifted by one); SpMV computes the column
+  // of the other rows instead of loading it, which removes most of the 4 B/entry index
+  // stream.  Slices with more than a quarter of their rows exceptional are flagged whole and
+  // behave as before.  NG_SPMV_OFFSETS=0 turns it off.
+  {
+    const bool on = !(getenv("NG_SPMV_OFFSETS") && atoi(getenv("NG_SPMV_OFFSETS")) == 0);
+    std::vector<int> kOff((size_t)(h->sellSize / SELL_C) + 1, 0);
+    std::vector<unsigned long long> ex((size_t)std::max(h->nSlices, 1) * 4, ~0ULL);
+    if (on)
+      parallel_for(h->nSlices, [&](int64_t a, int64_t b) {
+        std::vector<std::pair<int, int>> votes;
+        for (int64_t sl = a; sl < b; ++sl) {
+          const int r0 = (int)sl * SELL_C, r1 = std::min(nO, r0 + SELL_C), w = h->hSliceWidth[sl];
+          int *off = kOff.data() + h->hSliceOff[sl] / SELL_C;
+          unsigned long long m[4] = {0, 0, 0, 0};
+          for (int r = r1; r < r0 + SELL_C; ++r) m[(r - r0) >> 6] |= 1ULL << ((r - r0) & 63);
+          for (int k = 0; k < w; ++k) {
+            votes.clear();
+            for (int r = r0; r < r1; ++r) {
+              const int64_t len = h->rowPtr[r + 1] - h->rowPtr[r];
+              const int d = k < len ? h->colIdx[h->rowPtr[r] + k] - r : 0;  // padding: col = row
+              bool found = false;
+              for (auto &v : votes)
+                if (v.first == d) { ++v.second; found = true; break; }
+              if (!found && votes.size() < 16) votes.emplace_back(d, 1);
+            }
+            int best = 0, bv = -1;
+            for (auto &v : votes)
+              if (v.second > bv) { best = v.first; bv = v.second; }
+            off[k] = best;
+            for (int r = r0; r < r1; ++r) {
+              const int64_t len = h->rowPtr[r + 1] - h->rowPtr[r];
+              const int d = k < len ? h->colIdx[h->rowPtr[r] + k] - r : 0;
+              if (d != best) m[(r - r0) >> 6] |= 1ULL << ((r - r0) & 63);
+            }
+          }
+          const int nex = __builtin_popcountll(m[0]) + __builtin_popcountll(m[1]) +
+                          __builtin_popcountll(m[2]) + __builtin_popcountll(m[3]);
+          if (nex - (r0 + SELL_C - r1) <= SELL_C / 4)
+            for (int i = 0; i < 4; ++i) ex[(size_t)sl * 4 + i] = m[i];
+        }
+      });
+    NG_HIP(hipMalloc(&h->dKOff, sizeof(int) * kOff.size()));
+    NG_HIP(hipMalloc(&h->dExMask, sizeof(unsigned long long) * ex.size()));
+    NG_HIP(hipMemcpy(h->dKOff, kOff.data(), sizeof(int) * kOff.size(), hipMemcpyHostToDevice));
+    NG_HIP(hipMemcpy(h->dExMask, ex.data(), sizeof(unsigned long long) * ex.size(), hipMemcpyHostToDevice));
   }
 
   // slice schedule of the row kernels (tuning knob)

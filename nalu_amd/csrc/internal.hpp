@@ -35,6 +35,10 @@ struct SellView {
   double *vals;
   const unsigned *tags;
   int xcdRun;  // slice schedule of the row kernels (xcd_run): slices per XCD run, 0 = identity
+  // column-offset compression (see finalize): entry k of every row of slice s that is not
+  // flagged in exMask has column row + kOff[sliceOff[s] / C + k], so SpMV skips its cols load
+  const int *kOff;
+  const unsigned long long *exMask;  // 4 words per slice, bit r%64 of word r/64: row r reads cols
   int nSlices;
   int nRows;
 };
@@ -95,6 +99,8 @@ struct nalu_gpu_linsys {
   double *dVals = nullptr;
   unsigned *dTags = nullptr;
   int xcdRun = 8;  // slices per XCD run of the row-kernel schedule (NG_XCD_RUN)
+  int *dKOff = nullptr;
+  unsigned long long *dExMask = nullptr;
 
   // edges
   int *dEdgeL = nullptr, *dEdgeR = nullptr;
@@ -179,6 +185,8 @@ inline SellView sell_view(const nalu_gpu_linsys *h)
   v.vals = h->dVals;
   v.tags = h->dTags;
   v.xcdRun = h->xcdRun;
+  v.kOff = h->dKOff;
+  v.exMask = h->dExMask;
   v.nSlices = h->nSlices;
   v.nRows = h->nOwned;
   return v;

@@ -152,13 +152,14 @@ namespace {
 template <int W, bool DINV>
 __device__ __forceinline__ double row_chunk(const int *__restrict__ cols,
                                             const double *__restrict__ vals, long long pos,
+                                            const int *__restrict__ off, bool ex, int row,
                                             const double *__restrict__ x,
                                             const double *__restrict__ dinv, double sum)
 {
   int c[W];
   double v[W], xv[W];
 #pragma unroll
-  for (int j = 0; j < W; ++j) c[j] = cols[pos + (long long)j * SELL_C];
+  for (int j = 0; j < W; ++j) c[j] = ex ? cols[pos + (long long)j * SELL_C] : row + off[j];
 #pragma unroll
   for (int j = 0; j < W; ++j) v[j] = vals[pos + (long long)j * SELL_C];
 #pragma unroll
@@ -170,21 +171,22 @@ __device__ __forceinline__ double row_chunk(const int *__restrict__ cols,
 
 template <bool DINV>
 __device__ __forceinline__ double row_sum(const SellView &A, long long pos, int w,
+                                          const int *__restrict__ off, bool ex, int row,
                                           const double *__restrict__ x,
                                           const double *__restrict__ dinv)
 {
   double sum = 0.0;
   int k = 0;
-  for (; k + 8 <= w; k += 8, pos += 8LL * SELL_C)
-    sum = row_chunk<8, DINV>(A.cols, A.vals, pos, x, dinv, sum);
+  for (; k + 8 <= w; k += 8, pos += 8LL * SELL_C, off += 8)
+    sum = row_chunk<8, DINV>(A.cols, A.vals, pos, off, ex, row, x, dinv, sum);
   switch (w - k) {  // wave-uniform
-    case 7: sum = row_chunk<7, DINV>(A.cols, A.vals, pos, x, dinv, sum); break;
-    case 6: sum = row_chunk<6, DINV>(A.cols, A.vals, pos, x, dinv, sum); break;
-    case 5: sum = row_chunk<5, DINV>(A.cols, A.vals, pos, x, dinv, sum); break;
-    case 4: sum = row_chunk<4, DINV>(A.cols, A.vals, pos, x, dinv, sum); break;
-    case 3: sum = row_chunk<3, DINV>(A.cols, A.vals, pos, x, dinv, sum); break;
-    case 2: sum = row_chunk<2, DINV>(A.cols, A.vals, pos, x, dinv, sum); break;
-    case 1: sum = row_chunk<1, DINV>(A.cols, A.vals, pos, x, dinv, sum); break;
+    case 7: sum = row_chunk<7, DINV>(A.cols, A.vals, pos, off, ex, row, x, dinv, sum); break;
+    case 6: sum = row_chunk<6, DINV>(A.cols, A.vals, pos, off, ex, row, x, dinv, sum); break;
+    case 5: sum = row_chunk<5, DINV>(A.cols, A.vals, pos, off, ex, row, x, dinv, sum); break;
+    case 4: sum = row_chunk<4, DINV>(A.cols, A.vals, pos, off, ex, row, x, dinv, sum); break;
+    case 3: sum = row_chunk<3, DINV>(A.cols, A.vals, pos, off, ex, row, x, dinv, sum); break;
+    case 2: sum = row_chunk<2, DINV>(A.cols, A.vals, pos, off, ex, row, x, dinv, sum); break;
+    case 1: sum = row_chunk<1, DINV>(A.cols, A.vals, pos, off, ex, row, x, dinv, sum); break;
     default: break;
   }
   return sum;
@@ -205,7 +207,11 @@ __global__ __launch_bounds__(SELL_C) void k_spmv(SellView A, const double *__res
   if (sc && sc->done) return;
   const int s = list ? list[xcd_run(blockIdx.x, nList, run)] : xcd_run(blockIdx.x, A.nSlices, run);
   const int row = s * SELL_C + threadIdx.x;
-  const double sum = row_sum<DINV>(A, A.sliceOff[s] + threadIdx.x, A.sliceWidth[s], x, dinv);
+  const long long so = A.sliceOff[s];
+  const unsigned long long mask = A.exMask[(size_t)s * 4 + (threadIdx.x >> 6)];  // wave-uniform
+  const bool ex = (mask >> (threadIdx.x & 63)) & 1ULL;
+  const double sum = row_sum<DINV>(A, so + threadIdx.x, A.sliceWidth[s], A.kOff + so / SELL_C, ex, row,
+                                   x, dinv);
   double acc[1] = {0.0};
   if (row < A.nRows) {
     y[row] = sum;

@@ -445,3 +445,52 @@ def test_equation_system_driver(G, torch, oracle, tmp_path):
     assert eq.timerAssemble > 0 and eq.timerSolve > 0 and eq.timerLoadComplete >= 0
     import os
     assert os.path.exists(str(tmp_path / "ContinuityEQS-O-1.sln.1")) and g.writeCounter == 2
+
+
+@pytest.mark.parametrize("kind", ["random", "half"])
+def test_irregular_node_numbering(G, torch, oracle, kind):
+    """Nothing in the library may depend on lattice numbering: scrambled node ids (all slices
+    fall back to loaded column indices) and a half-scrambled mesh (slices with computed
+    column offsets next to exceptional ones).  Assembly to 1e-12 (the oracle's edge order is
+    no longer the row order), SpMV bit-exact on the oracle's own matrix values."""
+    c = Case(oracle, 9, 0.125)
+    n = c.m.nnodes
+    rs = np.random.RandomState(5)
+    perm = np.arange(n)
+    if kind == "random":
+        rs.shuffle(perm)
+    else:
+        perm[n // 2:] = n // 2 + rs.permutation(n - n // 2)
+    en = np.ascontiguousarray(perm[c.m.edge_nodes].astype(np.int32))  # new id of old node i = perm[i]
+    inv = np.argsort(perm)
+    f = lambda a: np.ascontiguousarray(a[inv])
+    ls = oracle.LinSys(1, n)
+    ls.add_connections(en)
+    ls.finalize()
+    ls.zero()
+    ls.assemble_continuity(en, c.area, f(c.m.xyz), f(c.dpdx), f(c.vel), f(c.p), f(c.rho), c.dt)
+    g = G.GpuLinearSystem()
+    g.beginLinearSystemConstruction(n)
+    g.buildEdgeToNodeGraph(en)
+    g.finalizeLinearSystem()
+    g.zeroSystem()
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+    soa = lambda a: t(f(a).T)
+    for mode in ("rows", "colored", "atomic"):
+        g.zeroSystem()
+        g.assemble_continuity_edges(soa(c.m.xyz), soa(c.dpdx), soa(c.vel), t(f(c.p)), t(f(c.rho)),
+                                    t(c.area.T), c.dt, mode=mode)
+        g.loadComplete()
+        _compare_system(g, ls, exact=False)
+    g.set_matrix_values(ls.owned_csr()[2])
+    x = rs.uniform(-1, 1, n)
+    y = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    g.spmv(t(x), y)
+    g.synchronize()
+    assert np.array_equal(y.cpu().numpy(), ls.spmv(x))
+    ref = ls.solve("gmres", "sgs", tolerance=1e-9, max_iterations=150, kspace=40)
+    g.set_rhs(ls.owned_rhs())
+    g.solve(G.LinearSolverConfig(method="gmres", preconditioner="sgs", tolerance=1e-9,
+                                 max_iterations=150, kspace=40))
+    assert g.linearSolveIterations == ref["iters"]
+    assert np.abs(g.history - ref["history"]).max() <= TOL_SOLVE
