@@ -252,17 +252,22 @@ __global__ __launch_bounds__(SELL_C) void k_assemble_rows(SellView A, typename O
   const int nLive = min(SELL_C, A.nRows - sBase);
   const long long off = A.sliceOff[slice];
   const int w = A.sliceWidth[slice];
+  // computed columns for the rows whose k-th column is row + kOff[k] (see finalize)
+  const int *kOff = A.kOff + off / SELL_C;
+  const bool ex = (A.exMask[(size_t)slice * 4 + (r >> 6)] >> (r & 63)) & 1ULL;
+  const unsigned *tBase = A.tBase + off / SELL_C, *tMul = A.tMul + off / SELL_C;
+  const bool exT = (A.exMaskT[(size_t)slice * 4 + (r >> 6)] >> (r & 63)) & 1ULL;
   double diag = 0.0, b = 0.0;
   long long diagPos = -1;
   for (int k = 0; k < w; ++k) {
     const long long pos = off + (long long)k * SELL_C + r;
-    const unsigned tag = A.tags[pos];
+    const unsigned tag = exT ? A.tags[pos] : tBase[k] + tMul[k] * (unsigned)row;
     if (tag >= TAG_OTHER) {
       if (tag == TAG_DIAG) diagPos = pos;
       else if (SET) A.vals[pos] = 0.0;
       continue;
     }
-    const int c = A.cols[pos];
+    const int c = ex ? A.cols[pos] : row + kOff[k];
     const long long e = tag & 0x7FFFFFFFu;
     const bool isR = (tag >> 31) != 0;
     Node nb;

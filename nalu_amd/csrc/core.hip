@@ -146,7 +146,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dTags); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
-  NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dReduce); NG_FREE(h->dScal);
+  NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   NG_FREE(h->dY); NG_FREE(h->dList); NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf);
   NG_FREE(h->dRecvBuf);
@@ -338,6 +338,48 @@ __global__ void k_tag_edges(long long nEdges, const int *eL, const int *eR, int 
   }
 }
 
+// Tag-offset compression (the assembly kernels' counterpart of the column offsets, see
+// finalize): per (slice, k) find (mul, base) with tag = base + mul * row for most rows --
+// (0, DIAG/PAD/OTHER) for the special tags, (1, tag - row) when the caller numbered the edges
+// along the rows (slot-major) -- and flag the rows that deviate.  Candidates are the keys of
+// four sample lanes; the one most rows agree with wins.  A slice with more than a quarter of
+// its rows flagged is flagged whole.
+__global__ __launch_bounds__(SELL_C) void k_tag_offsets(int nRows, const long long *sliceOff,
+                                                         const int *sliceWidth, const unsigned *tags,
+                                                         unsigned *tBase, unsigned *tMul,
+                                                         unsigned long long *exMaskT, int enabled)
+{
+  __shared__ unsigned sMul[4], sBase[4];
+  const int slice = blockIdx.x, r = threadIdx.x;
+  const int row = slice * SELL_C + r;
+  const bool live = row < nRows;
+  const long long off = sliceOff[slice];
+  const int w = sliceWidth[slice];
+  bool ex = !live;
+  for (int k = 0; k < w && enabled; ++k) {
+    const unsigned tag = tags[off + (long long)k * SELL_C + r];
+    const unsigned mul = tag >= TAG_OTHER ? 0u : 1u;
+    const unsigned base = tag - mul * (unsigned)row;
+    if ((r & 63) == 32) { sMul[r >> 6] = mul; sBase[r >> 6] = base; }
+    __syncthreads();
+    int best = 0, bestCnt = -1;
+    for (int c = 0; c < 4; ++c) {
+      const int cnt = __syncthreads_count(live && mul == sMul[c] && base == sBase[c]);
+      if (cnt > bestCnt) { bestCnt = cnt; best = c; }
+    }
+    if (mul != sMul[best] || base != sBase[best]) ex = true;
+    if (r == 0) {
+      tBase[off / SELL_C + k] = sBase[best];
+      tMul[off / SELL_C + k] = sMul[best];
+    }
+    __syncthreads();
+  }
+  const int nex = __syncthreads_count(ex && live);
+  if (!enabled || nex > SELL_C / 4) ex = true;
+  const unsigned long long m = __ballot(ex);
+  if ((r & 63) == 0) exMaskT[(size_t)slice * 4 + (r >> 6)] = m;
+}
+
 extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
 {
   NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
@@ -519,6 +561,18 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
     (void)hipFree(dErr);
     NG_REQUIRE(err[0] == 0, NALU_GPU_EINVAL, "internal: %d edge entries missing from the graph", err[0]);
     NG_REQUIRE(err[1] == 0, NALU_GPU_EINVAL, "%d duplicate edges (same node pair twice)", err[1]);
+  }
+  {
+    const size_t nk = (size_t)(h->sellSize / SELL_C) + 1;
+    NG_HIP(hipMalloc(&h->dTBase, sizeof(unsigned) * nk));
+    NG_HIP(hipMalloc(&h->dTMul, sizeof(unsigned) * nk));
+    NG_HIP(hipMalloc(&h->dExMaskT, sizeof(unsigned long long) * (size_t)std::max(h->nSlices, 1) * 4));
+    NG_HIP(hipMemsetAsync(h->dExMaskT, 0xFF, sizeof(unsigned long long) * (size_t)std::max(h->nSlices, 1) * 4, h->stream));
+    const int on = !(getenv("NG_TAG_OFFSETS") && atoi(getenv("NG_TAG_OFFSETS")) == 0);
+    if (h->nSlices > 0)
+      k_tag_offsets<<<h->nSlices, SELL_C, 0, h->stream>>>(nO, h->dSliceOff, h->dSliceWidth, h->dTags,
+                                                          h->dTBase, h->dTMul, h->dExMaskT, on);
+    NG_HIP(hipGetLastError());
   }
   // entity lists are no longer needed
   std::vector<EntBlock>().swap(h->blocks);

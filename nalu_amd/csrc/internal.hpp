@@ -39,6 +39,10 @@ struct SellView {
   // flagged in exMask has column row + kOff[sliceOff[s] / C + k], so SpMV skips its cols load
   const int *kOff;
   const unsigned long long *exMask;  // 4 words per slice, bit r%64 of word r/64: row r reads cols
+  // the same for the edge tags: tag = tBase + tMul * row (tMul 0 for DIAG/PAD/OTHER, 1 for edges
+  // numbered along the rows) unless the row is flagged in exMaskT
+  const unsigned *tBase, *tMul;
+  const unsigned long long *exMaskT;
   int nSlices;
   int nRows;
 };
@@ -100,7 +104,8 @@ struct nalu_gpu_linsys {
   unsigned *dTags = nullptr;
   int xcdRun = 8;  // slices per XCD run of the row-kernel schedule (NG_XCD_RUN)
   int *dKOff = nullptr;
-  unsigned long long *dExMask = nullptr;
+  unsigned long long *dExMask = nullptr, *dExMaskT = nullptr;
+  unsigned *dTBase = nullptr, *dTMul = nullptr;
 
   // edges
   int *dEdgeL = nullptr, *dEdgeR = nullptr;
@@ -187,6 +192,9 @@ inline SellView sell_view(const nalu_gpu_linsys *h)
   v.xcdRun = h->xcdRun;
   v.kOff = h->dKOff;
   v.exMask = h->dExMask;
+  v.tBase = h->dTBase;
+  v.tMul = h->dTMul;
+  v.exMaskT = h->dExMaskT;
   v.nSlices = h->nSlices;
   v.nRows = h->nOwned;
   return v;
