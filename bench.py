@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--mode", default="rows", choices=["rows", "colored", "atomic"])
     ap.add_argument("--cpu-n", type=int, default=128, help="box size of the CPU baseline sample (0 = skip)")
     ap.add_argument("--variants", action="store_true", help="also time the colored/atomic scatter variants")
+    ap.add_argument("--workload", default="continuity", choices=["continuity", "scalar"],
+                    help="continuity = the headline Poisson step (default); scalar = BASELINE config 4: "
+                         "scalar transport edge assembly (upwind, limiter) + mass term + GMRES(50)/Jacobi")
     a = ap.parse_args()
 
     import torch
@@ -148,6 +151,23 @@ def main():
         S.edge_nodes, F, dt=0.1, gamma1=1.0, noc=1.0, interp_together=1.0, mode=a.mode)
     eq.solverAlgDriver.solverAlgMap["REF_PRESSURE"] = eqsys.FixPressureAtNodeAlgorithm(
         0 if pin else None, 0.0, p0)
+
+    if a.workload == "scalar":
+        from nalu_amd import synth
+        xyz = S.coords()
+        t64 = lambda v: torch.as_tensor(np.ascontiguousarray(v), dtype=torch.float64, device=device)
+        vol, _ = S.uniform_geometry()
+        F.update(q=t64(synth.quadratic(xyz.T, 1)), dqdx=t64(synth.quadratic_grad(xyz.T, 1).T),
+                 gamma=t64(np.full(S.n_local, 0.2)), vol=t64(vol),
+                 mdot=torch.empty(S.n_edges, dtype=torch.float64, device=device))
+        g.compute_mdot_edges(F["coords"], F["dpdx"], F["vel"], F["p"], F["rho"], F["area"], 0.1, F["mdot"])
+        cfg = nalu_amd.LinearSolverConfig(method="gmres", preconditioner="jacobi", tolerance=1e-5,
+                                          max_iterations=50, kspace=50)
+        eq = eqsys.EquationSystem(g, cfg, "MixtureFractionEQS")
+        eq.solverAlgDriver.solverAlgMap["INTERIOR"] = eqsys.AssembleScalarEdgeSolverAlgorithm(
+            S.edge_nodes, F, mode=a.mode, hybrid_factor=1.0, alpha_upw=1.0, upw_factor=1.0, limiter=True)
+        eq.solverAlgDriver.solverAlgMap["MASS"] = eqsys.ScalarMassBackwardEulerAlgorithm(
+            None, 0.9 * F["q"], F["q"], F["rho"], F["rho"], F["vol"], 0.1)
 
     def step():
         eq.assemble_and_solve()  # src/EquationSystem.C:263-307
@@ -180,7 +200,7 @@ def main():
 
     # algorithmic bytes: per-rank local sizes
     Nl, El, nnzl = S.n_owned, S.n_edges, g.nnz
-    asm_bytes = 32 * El + 96 * Nl + 8 * nnzl
+    asm_bytes = (40 * El + 104 * Nl if a.workload == "scalar" else 32 * El + 96 * Nl) + 8 * nnzl
     spmv_bytes = 12 * nnzl + 4 * (Nl + 1) + 16 * Nl
     asm_t = asm_ms / max(asm_cnt, 1) * 1e-3
     spmv_t = spmv_ms / max(spmv_cnt, 1) * 1e-3
@@ -211,19 +231,24 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"Hex8 box {n}^3 nodes per GPU ({n}x{n}x{n * world} total): continuity "
-                                   "edge assembly + pinned node + Jacobi-CG (tol 1e-5, max_it 50)",
-                       "nodes": Ng, "edges": Eg, "scatter": a.mode, "cg_iterations": iters,
+            "config": {"workload": f"Hex8 box {n}^3 nodes per GPU ({n}x{n}x{n * world} total): " + (
+                           "continuity edge assembly + pinned node + Jacobi-CG (tol 1e-5, max_it 50)"
+                           if a.workload == "continuity" else
+                           "scalar transport edge assembly (upwind, van Leer limiter) + mass term + "
+                           "GMRES(50)/Jacobi (tol 1e-5, max_it 50)"),
+                       "nodes": Ng, "edges": Eg, "scatter": a.mode, "solver_iterations": iters,
                        "parallelism": f"z-slabs x{world}"},
-            "roofline": {"kernel": "k_spmv<DOT> (SELL-256 SpMV fused with p.Ap)", "bound": "hbm",
+            "roofline": {"kernel": "k_spmv<DOT> (SELL-256 SpMV fused with p.Ap)" if a.workload == "continuity"
+                         else "k_spmv<DINV> (SELL-256 SpMV with the right-preconditioner column scaling)",
+                         "bound": "hbm",
                          "achieved": spmv_bytes / spmv_t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": spmv_bytes / spmv_t / 1e9 / HBM_PEAK_GBS,
                          "traffic": pmc.get("k_spmv", {}).get("hbm_bytes"),
                          "algorithmic_bytes": spmv_bytes, "avg_ms": spmv_t * 1e3, "launches": spmv_cnt},
-            "roofline_assembly": {"kernel": f"k_assemble_rows<ContOp> ({a.mode})", "bound": "hbm",
+            "roofline_assembly": {"kernel": f"k_assemble_rows<{'ContOp' if a.workload == 'continuity' else 'ScalOp'}> ({a.mode})", "bound": "hbm",
                                   "achieved": asm_bytes / asm_t / 1e9, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": asm_bytes / asm_t / 1e9 / HBM_PEAK_GBS,
-                                  "traffic": pmc.get("k_assemble_rows", {}).get("hbm_bytes"),
+                                  "traffic": pmc.get("k_assemble_rows", {}).get("hbm_bytes") if a.workload == "continuity" else None,
                                   "algorithmic_bytes": asm_bytes,
                                   "avg_ms": asm_t * 1e3, "launches": asm_cnt,
                                   "edges_per_s_per_gpu": El / asm_t},
