@@ -143,7 +143,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   drain_timers(h);
   for (hipEvent_t e : h->eventPool) (void)hipEventDestroy(e);
   NG_FREE(h->dSliceOff); NG_FREE(h->dSliceWidth); NG_FREE(h->dCols); NG_FREE(h->dVals);
-  NG_FREE(h->dTags); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
+  NG_FREE(h->dTags); NG_FREE(h->dDiagPos); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
   NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dReduce); NG_FREE(h->dScal);
@@ -380,6 +380,21 @@ __global__ __launch_bounds__(SELL_C) void k_tag_offsets(int nRows, const long lo
   if ((r & 63) == 0) exMaskT[(size_t)slice * 4 + (r >> 6)] = m;
 }
 
+__global__ __launch_bounds__(SELL_C) void k_find_diag(int nRows, const long long *sliceOff,
+                                                       const int *sliceWidth, const unsigned *tags,
+                                                       long long *diagPos)
+{
+  const int slice = blockIdx.x, r = threadIdx.x;
+  const int row = slice * SELL_C + r;
+  if (row >= nRows) return;
+  const long long off = sliceOff[slice];
+  const int w = sliceWidth[slice];
+  long long p = -1;
+  for (int k = 0; k < w; ++k)
+    if (tags[off + (long long)k * SELL_C + r] == TAG_DIAG) p = off + (long long)k * SELL_C + r;
+  diagPos[row] = p;
+}
+
 extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
 {
   NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
@@ -574,6 +589,10 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
                                                           h->dTBase, h->dTMul, h->dExMaskT, on);
     NG_HIP(hipGetLastError());
   }
+  NG_HIP(hipMalloc(&h->dDiagPos, sizeof(long long) * (size_t)std::max(nO, 1)));
+  if (h->nSlices > 0)
+    k_find_diag<<<h->nSlices, SELL_C, 0, h->stream>>>(nO, h->dSliceOff, h->dSliceWidth, h->dTags, h->dDiagPos);
+  NG_HIP(hipGetLastError());
   // entity lists are no longer needed
   std::vector<EntBlock>().swap(h->blocks);
 

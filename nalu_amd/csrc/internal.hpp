@@ -102,6 +102,7 @@ struct nalu_gpu_linsys {
   int *dCols = nullptr;
   double *dVals = nullptr;
   unsigned *dTags = nullptr;
+  long long *dDiagPos = nullptr;  // SELL position of each row's diagonal entry (-1: none)
   int xcdRun = 8;  // slices per XCD run of the row-kernel schedule (NG_XCD_RUN)
   int *dKOff = nullptr;
   unsigned long long *dExMask = nullptr, *dExMaskT = nullptr;

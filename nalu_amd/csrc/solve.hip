@@ -83,12 +83,12 @@ __global__ __launch_bounds__(RED_T) void k_reduce_partials(const double *__restr
   for (int slot = 0; slot < nslots; ++slot) {
     const double *p = partials + (size_t)slot * MAX_BLOCKS;
     double v = 0.0;
-    for (int i0 = threadIdx.x; i0 < nblocks; i0 += RED_T * 8) {  // 8 loads in flight, fixed add order
-      double t[8];
+    for (int i0 = threadIdx.x; i0 < nblocks; i0 += RED_T * 16) {  // 16 loads in flight, fixed add order
+      double t[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = (i0 + u * RED_T < nblocks) ? p[i0 + u * RED_T] : 0.0;
+      for (int u = 0; u < 16; ++u) t[u] = (i0 + u * RED_T < nblocks) ? p[i0 + u * RED_T] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v += t[u];
+      for (int u = 0; u < 16; ++u) v += t[u];
     }
     s[threadIdx.x] = v;
     __syncthreads();
@@ -271,23 +271,19 @@ __global__ __launch_bounds__(256) void k_axpy(long long n, double alpha, const d
   GRID_STRIDE(i, n) y[i] += alpha * x[i];
 }
 
-// dinv = 1/diag(A) (Ifpack2 Jacobi compute(): diagonal extraction), or 1 without precond
-__global__ __launch_bounds__(SELL_C) void k_extract_dinv(SellView A, int jacobi,
-                                                          double *__restrict__ dinv)
+// dinv = 1/diag(A) (Ifpack2 Jacobi compute(): diagonal extraction), or 1 without precond.
+// diagPos holds the SELL position of every row's diagonal entry (-1: none), found once at
+// finalize, so this reads one value per row instead of scanning the row's tags.
+__global__ __launch_bounds__(256) void k_extract_dinv(int nRows, const long long *__restrict__ diagPos,
+                                                       const double *__restrict__ vals, int jacobi,
+                                                       double *__restrict__ dinv)
 {
-  const int slice = blockIdx.x, r = threadIdx.x;
-  const int row = slice * SELL_C + r;
-  if (row >= A.nRows) return;
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nRows) return;
   double d = 1.0;
   if (jacobi) {
-    const long long off = A.sliceOff[slice];
-    const int w = A.sliceWidth[slice];
-    d = 0.0;
-    for (int k = 0; k < w; ++k) {
-      const long long pos = off + (long long)k * SELL_C + r;
-      if (A.tags[pos] == TAG_DIAG) d = A.vals[pos];
-    }
-    d = 1.0 / d;
+    const long long pos = diagPos[row];
+    d = 1.0 / (pos >= 0 ? vals[pos] : 0.0);
   }
   dinv[row] = d;
 }
@@ -870,8 +866,10 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
   // preconditioner_->compute() (src/LinearSolver.C:205), timed like timerPrecond_ (:195-211)
   const auto t0 = std::chrono::steady_clock::now();
   timer_begin(h, NALU_GPU_T_PRECOND);
-  if (h->nSlices)
-    k_extract_dinv<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), cfg->precond != NALU_GPU_PRECOND_NONE, h->dDinv);
+  if (h->nOwned)
+    k_extract_dinv<<<(h->nOwned + 255) / 256, 256, 0, h->stream>>>(h->nOwned, h->dDiagPos, h->dVals,
+                                                                   cfg->precond != NALU_GPU_PRECOND_NONE,
+                                                                   h->dDinv);
   if (cfg->precond == NALU_GPU_PRECOND_SGS) NG_TRY(ensure_sgs_levels(h));
   NG_HIP(hipGetLastError());
   NG_TRY(halo_exchange(h, h->dDinv));
