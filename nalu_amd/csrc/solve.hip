@@ -205,6 +205,12 @@ __global__ __launch_bounds__(SELL_C) void k_spmv(SellView A, const double *__res
                                                   const int *__restrict__ list, int nList)
 {
   if (sc && sc->done) return;
+  __shared__ double sWave[SELL_C / 64];
+  __shared__ int sTicket;
+  if (DOT) {  // all waves are here at launch: this barrier costs nothing
+    if (threadIdx.x == 0) sTicket = 0;
+    __syncthreads();
+  }
   const int s = list ? list[xcd_run(blockIdx.x, nList, run)] : xcd_run(blockIdx.x, A.nSlices, run);
   const int row = s * SELL_C + threadIdx.x;
   const long long so = A.sliceOff[s];
@@ -212,12 +218,26 @@ __global__ __launch_bounds__(SELL_C) void k_spmv(SellView A, const double *__res
   const bool ex = (mask >> (threadIdx.x & 63)) & 1ULL;
   const double sum = row_sum<DINV>(A, so + threadIdx.x, A.sliceWidth[s], A.kOff + so / SELL_C, ex, row,
                                    x, dinv);
-  double acc[1] = {0.0};
+  double prod = 0.0;
   if (row < A.nRows) {
     y[row] = sum;
-    if (DOT) acc[0] = x[row] * sum;
+    if (DOT) prod = x[row] * sum;
   }
-  if (DOT) block_sums<1>(acc, partials, 1, s);
+  if (DOT) {
+    // barrier-free epilogue: every wave leaves its sum in LDS and takes a ticket; the wave
+    // that draws the last ticket adds the four sums in wave order (the others are gone by
+    // then, they do not wait for the slowest wave of the workgroup)
+    const double t = wave_sum(prod);
+    if ((threadIdx.x & 63) == 0) {
+      sWave[threadIdx.x >> 6] = t;
+      __threadfence_block();
+      if (atomicAdd(&sTicket, 1) == SELL_C / 64 - 1) {
+        __threadfence_block();  // acquire: the other waves' sums are in LDS
+        const volatile double *w = sWave;
+        partials[s] = ((w[0] + w[1]) + w[2]) + w[3];
+      }
+    }
+  }
 }
 
 // DOT: the partials land in h->dSlicePartials[0 .. *nblocks).  list != nullptr: only the
