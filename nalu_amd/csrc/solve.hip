@@ -204,7 +204,9 @@ __global__ __launch_bounds__(SELL_C) void k_spmv(SellView A, const double *__res
                                                   const SolverScalars *__restrict__ sc, int run,
                                                   const int *__restrict__ list, int nList)
 {
-  if (sc && sc->done) return;
+  // the done flag is only needed before the stores: let its load overlap the matrix loads
+  // (a workgroup lives a few microseconds; a dependent L2 round trip up front is not free)
+  const int stop = sc ? sc->done : 0;
   __shared__ double sWave[SELL_C / 64];
   __shared__ int sTicket;
   if (DOT) {  // all waves are here at launch: this barrier costs nothing
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(SELL_C) void k_spmv(SellView A, const double *__res
   const bool ex = (mask >> (threadIdx.x & 63)) & 1ULL;
   const double sum = row_sum<DINV>(A, so + threadIdx.x, A.sliceWidth[s], A.kOff + so / SELL_C, ex, row,
                                    x, dinv);
+  if (stop) return;
   double prod = 0.0;
   if (row < A.nRows) {
     y[row] = sum;
