@@ -607,7 +607,7 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
   NG_HIP(hipMalloc(&h->dW, sizeof(double) * nC));
   NG_HIP(hipMalloc(&h->dT, sizeof(double) * nC));
   NG_HIP(hipMalloc(&h->dPartials, sizeof(double) * PARTIAL_SLOTS * MAX_BLOCKS));
-  NG_HIP(hipMalloc(&h->dSlicePartials, sizeof(double) * std::max(h->nSlices, 1)));
+  NG_HIP(hipMalloc(&h->dSlicePartials, sizeof(double) * (std::max(h->nSlices, 1) + 64)));  // + pre-reduction
 
   // slices whose rows read shared/ghost columns ("boundary") and the rest ("interior"): the
   // SpMV of the interior slices overlaps the halo exchange (Tpetra's Import in apply)

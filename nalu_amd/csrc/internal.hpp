@@ -126,7 +126,7 @@ struct nalu_gpu_linsys {
   double *dV = nullptr;  // GMRES basis, (kspace+1) x nCols
   int vCap = 0;
   double *dPartials = nullptr;  // PARTIAL_SLOTS x MAX_BLOCKS
-  double *dSlicePartials = nullptr;  // nSlices: per-slice partials of the SpMV-fused dot
+  double *dSlicePartials = nullptr;  // nSlices (+64): per-slice partials of the SpMV-fused dot
   int *dSliceLists = nullptr;        // interior slices, then boundary slices (multi-rank only)
   int nInterior = 0, nBoundary = 0;
   double *dReduce = nullptr;    // REDUCE_CAP

@@ -105,6 +105,42 @@ __global__ __launch_bounds__(RED_T) void k_reduce_partials(const double *__restr
   }
 }
 
+// first stage for long partial lists (the SpMV-fused dot leaves one partial per slice, 65,536
+// at 256^3, and a single workgroup reads them at single-CU bandwidth): PRE_WG workgroups sum
+// contiguous chunks in a fixed order
+constexpr int PRE_WG = 64;
+__global__ __launch_bounds__(256) void k_prereduce(const double *__restrict__ src, int n,
+                                                    double *__restrict__ dst,
+                                                    const SolverScalars *__restrict__ sc)
+{
+  if (sc && sc->done) return;
+  __shared__ double s[256];
+  const int chunk = (n + PRE_WG - 1) / PRE_WG;
+  const int i0 = blockIdx.x * chunk, i1 = min(n, i0 + chunk);
+  double v = 0.0;
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) v += src[i];
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dst[blockIdx.x] = s[0];
+}
+
+// slice partials -> at most PRE_WG partials (in place behind the slice partials)
+int prereduce_slices(nalu_gpu_linsys *h, int *count, const double **src, bool useDone)
+{
+  *src = h->dSlicePartials;
+  if (*count <= 4096) return NALU_GPU_OK;
+  double *dst = h->dSlicePartials + h->nSlices;
+  k_prereduce<<<PRE_WG, 256, 0, h->stream>>>(h->dSlicePartials, *count, dst, useDone ? h->dScal : nullptr);
+  NG_HIP(hipGetLastError());
+  *src = dst;
+  *count = PRE_WG;
+  return NALU_GPU_OK;
+}
+
 int reduce_partials(nalu_gpu_linsys *h, int nslots, int nblocks, int outOffset,
                     const double *src = nullptr)
 {
@@ -583,12 +619,13 @@ int solve_cg(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEve
   for (int it = 0; it < cfg->max_iterations; ++it) {
     int sb = 0;
     NG_TRY((spmv_with_halo<true, false>(h, h->dP, h->dQ, true, &sb)));
+    const double *pp = nullptr;
+    NG_TRY(prereduce_slices(h, &sb, &pp, true));
     if (h->hasComm) {
-      NG_TRY(finish_reduction(h, 1, sb, h->dSlicePartials));
+      NG_TRY(finish_reduction(h, 1, sb, pp));
       k_cg_scal_a<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
     } else {
-      k_reduce_partials<EPI_CG_A><<<1, RED_T, 0, h->stream>>>(h->dSlicePartials, sb, 1, h->dReduce,
-                                                            h->dScal, nullptr);
+      k_reduce_partials<EPI_CG_A><<<1, RED_T, 0, h->stream>>>(pp, sb, 1, h->dReduce, h->dScal, nullptr);
     }
     k_cg_update<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dDinv, h->dQ, h->dR, h->dPartials);
     if (h->hasComm) {
@@ -697,7 +734,9 @@ int solve_cg_sgs(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int chec
   for (int it = 0; it < cfg->max_iterations; ++it) {
     int sb = 0;
     NG_TRY((spmv_with_halo<true, false>(h, h->dP, h->dQ, true, &sb)));
-    NG_TRY(finish_reduction(h, 1, sb, h->dSlicePartials));
+    const double *pp = nullptr;
+    NG_TRY(prereduce_slices(h, &sb, &pp, true));
+    NG_TRY(finish_reduction(h, 1, sb, pp));
     k_cg_scal_a<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
     k_pcg_update<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dP, h->dQ, h->dX, h->dR, h->dPartials);
     NG_TRY(finish_reduction(h, 1, vb));
