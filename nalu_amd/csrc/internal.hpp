@@ -57,7 +57,7 @@ struct Timer {
   long long count = 0;
 };
 
-constexpr int MAX_BLOCKS = 2048;  // capped grids: 256 CUs x 8 workgroups
+constexpr int MAX_BLOCKS = 16384;  // cap of the reduction kernels' grids (partials per slot)
 constexpr int REDUCE_CAP = 256;   // doubles in the reduce buffer
 constexpr int PARTIAL_SLOTS = 8;  // simultaneous reductions per kernel
 

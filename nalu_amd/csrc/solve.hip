@@ -70,8 +70,8 @@ __device__ __forceinline__ void cg_scal_b(SolverScalars *sc, const double *red, 
 
 enum { EPI_NONE = 0, EPI_CG_A = 1, EPI_CG_B = 2 };
 
-// one workgroup: fixed-order sum of the per-workgroup partials of every slot, then
-// (optionally) the scalar recurrence that consumes the sums
+// fixed-order sum of the per-workgroup partials of every slot (one workgroup per slot, or one
+// workgroup for all slots followed by the scalar recurrence that consumes the sums)
 constexpr int RED_T = 1024;
 template <int EPI>
 __global__ __launch_bounds__(RED_T) void k_reduce_partials(const double *__restrict__ partials,
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(RED_T) void k_reduce_partials(const double *__restr
                                                           SolverScalars *sc, double *hist)
 {
   __shared__ double s[RED_T];
-  for (int slot = 0; slot < nslots; ++slot) {
+  for (int slot = blockIdx.x; slot < nslots; slot += gridDim.x) {  // epilogues need a grid of 1
     const double *p = partials + (size_t)slot * MAX_BLOCKS;
     double v = 0.0;
     for (int i0 = threadIdx.x; i0 < nblocks; i0 += RED_T * 16) {  // 16 loads in flight, fixed add order
@@ -144,7 +144,7 @@ int prereduce_slices(nalu_gpu_linsys *h, int *count, const double **src, bool us
 int reduce_partials(nalu_gpu_linsys *h, int nslots, int nblocks, int outOffset,
                     const double *src = nullptr)
 {
-  k_reduce_partials<EPI_NONE><<<1, RED_T, 0, h->stream>>>(src ? src : h->dPartials, nblocks, nslots,
+  k_reduce_partials<EPI_NONE><<<nslots, RED_T, 0, h->stream>>>(src ? src : h->dPartials, nblocks, nslots,
                                                         h->dReduce + outOffset, nullptr, nullptr);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
@@ -162,7 +162,8 @@ int allreduce(nalu_gpu_linsys *h, int count)
 
 int nalu_gpu::vec_grid(int64_t n)
 {
-  const int64_t nb = (n + 1023) / 1024;  // ~4 elements per thread at least
+  static const int per = getenv("NG_VEC_PER") ? std::max(1, atoi(getenv("NG_VEC_PER"))) : 4;
+  const int64_t nb = (n + 256 * per - 1) / (256 * per);  // elements per thread (at least)
   return (int)std::max<int64_t>(1, std::min<int64_t>(nb, MAX_BLOCKS));
 }
 
@@ -610,6 +611,10 @@ int solve_cg(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEve
 {
   const long long n = h->nOwned;
   const int vb = vec_grid(n);
+  // kernels without a reduction are not bound to the partial-sum layout: one element per
+  // thread streams a few % faster than a 2048-workgroup grid-stride loop (scripts/membench)
+  static const int pbDiv = getenv("NG_P_DIV") ? atoi(getenv("NG_P_DIV")) : 1;
+  const int pb = (int)std::max<long long>(1, std::min<long long>((n + 256LL * pbDiv - 1) / (256LL * pbDiv), 1 << 22));
   k_cg_init<<<vb, 256, 0, h->stream>>>(n, h->dRhs, h->dDinv, h->dX, h->dR, h->dP, h->dPartials);
   NG_HIP(hipGetLastError());
   NG_TRY(finish_reduction(h, 2, vb));
@@ -635,7 +640,7 @@ int solve_cg(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEve
       k_reduce_partials<EPI_CG_B><<<1, RED_T, 0, h->stream>>>(h->dPartials, vb, 2, h->dReduce,
                                                             h->dScal, h->dHist);
     }
-    k_cg_p<<<vb, 256, 0, h->stream>>>(n, h->dScal, it, h->dDinv, h->dR, h->dX, h->dP);
+    k_cg_p<<<pb, 256, 0, h->stream>>>(n, h->dScal, it, h->dDinv, h->dR, h->dX, h->dP);
     NG_HIP(hipGetLastError());
     if ((it + 1) % checkEvery == 0 && it + 1 < cfg->max_iterations) {
       NG_TRY(read_scalars(h, &sc));
