@@ -144,6 +144,11 @@ struct nalu_gpu_linsys {
   std::vector<int> sgsFwdOff, sgsBwdOff;
   int *dSgsFwdRows = nullptr, *dSgsBwdRows = nullptr;
 
+  // Chebyshev preconditioner (solve.hip)
+  double *dChebV = nullptr;      // nOwned
+  double *dChebStart = nullptr;  // nCols: power-method start vector (hash of the global ids)
+  double chebLambdaMax = 0.0;
+
   // halo
   int nNbr = 0;
   std::vector<int> nbrRanks, sendOff, recvOff;

@@ -348,6 +348,147 @@ __global__ __launch_bounds__(256) void k_extract_dinv(int nRows, const long long
   dinv[row] = d;
 }
 
+// ------------------------------------------------------------------- Chebyshev
+// Polynomial preconditioner on D^-1 A: Ifpack2::Details::Chebyshev (ifpackApplyImpl and
+// powerMethod; Trilinos, not in the reference tree: parity unpinned) with the parameters of
+// the reference's MueLu smoother block reg_tests/xml/milestone.xml:5-12 -- degree 2,
+// eigenvalue ratio 20, 15 power iterations, zero starting solution -- and Ifpack2's boost
+// factor 1.1.  The reference has no Ifpack2-level Chebyshev option; this is the SpMV-only
+// alternative to SGS that BASELINE's north star asks for.  The power method starts from a
+// fixed hash of the global node ids (Ifpack2: a random vector) so runs are reproducible.
+constexpr int CHEB_DEGREE = 2, CHEB_POWER_ITS = 15;
+constexpr double CHEB_RATIO = 20.0, CHEB_BOOST = 1.1;
+
+double cheb_start_value(int64_t gid)
+{
+  uint32_t v = (uint32_t)gid * 2654435761u;
+  v ^= v >> 16; v *= 0x85ebca6bu; v ^= v >> 13; v *= 0xc2b2ae35u; v ^= v >> 16;
+  return (double)v / 4294967296.0 * 2.0 - 1.0;
+}
+
+// y = dinv .* y and the partial sums of y.x, x.x, y.y
+__global__ __launch_bounds__(256) void k_cheb_power(long long n, const double *__restrict__ dinv,
+                                                     const double *__restrict__ x, double *__restrict__ y,
+                                                     double *__restrict__ partials)
+{
+  double acc[3] = {0.0, 0.0, 0.0};
+  GRID_STRIDE(i, n) {
+    const double yi = dinv[i] * y[i], xi = x[i];
+    y[i] = yi;
+    acc[0] += yi * xi;
+    acc[1] += xi * xi;
+    acc[2] += yi * yi;
+  }
+  block_sums<3>(acc, partials, 3);
+}
+
+__global__ __launch_bounds__(256) void k_div_copy(long long n, const double *__restrict__ y, double d,
+                                                   double *__restrict__ x)
+{
+  GRID_STRIDE(i, n) x[i] = y[i] / d;
+}
+
+// w = (dinv .* r) / theta ; x = w
+__global__ __launch_bounds__(256) void k_cheb_first(long long n, const SolverScalars *__restrict__ sc,
+                                                     double oneOverTheta, const double *__restrict__ dinv,
+                                                     const double *__restrict__ r, double *__restrict__ w,
+                                                     double *__restrict__ x)
+{
+  if (sc && sc->done) return;
+  GRID_STRIDE(i, n) {
+    const double wi = oneOverTheta * (dinv[i] * r[i]);
+    w[i] = wi;
+    x[i] = wi;
+  }
+}
+
+// w = d1 w + d2 dinv .* (r - v) ; x += w
+__global__ __launch_bounds__(256) void k_cheb_step(long long n, const SolverScalars *__restrict__ sc,
+                                                    double d1, double d2, const double *__restrict__ dinv,
+                                                    const double *__restrict__ r,
+                                                    const double *__restrict__ v, double *__restrict__ w,
+                                                    double *__restrict__ x)
+{
+  if (sc && sc->done) return;
+  GRID_STRIDE(i, n) {
+    const double wi = d1 * w[i] + d2 * (dinv[i] * (r[i] - v[i]));
+    w[i] = wi;
+    x[i] = x[i] + wi;
+  }
+}
+
+// Ifpack2 compute(): lambda_max(D^-1 A) by the power method; dDinv is ready
+int cheb_compute(nalu_gpu_linsys *h)
+{
+  const long long n = h->nOwned;
+  const int vb = vec_grid(n);
+  if (!h->dChebV) NG_HIP(hipMalloc(&h->dChebV, sizeof(double) * (size_t)std::max<long long>(n, 1)));
+  if (!h->dChebStart) {
+    std::vector<double> st((size_t)std::max(h->nCols, 1), 0.0);
+    for (int i = 0; i < h->nOwned; ++i) st[i] = cheb_start_value(h->gids[i]);
+    NG_HIP(hipMalloc(&h->dChebStart, sizeof(double) * st.size()));
+    NG_HIP(hipMemcpy(h->dChebStart, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice));
+  }
+  double *x = h->dP, *y = h->dChebV;
+  double *pin = (double *)((char *)h->hPinned + 2048);
+  auto fetch = [&](int cnt) -> int {
+    NG_HIP(hipMemcpyAsync(pin, h->dReduce, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    NG_HIP(hipStreamSynchronize(h->stream));
+    return NALU_GPU_OK;
+  };
+  k_dot<<<vb, 256, 0, h->stream>>>(n, h->dChebStart, h->dChebStart, h->dPartials);
+  NG_TRY(finish_reduction(h, 1, vb));
+  NG_TRY(fetch(1));
+  double norm = std::sqrt(pin[0]), lambda = 0.0;
+  if (norm != 0.0) {
+    k_div_copy<<<vb, 256, 0, h->stream>>>(n, h->dChebStart, norm, x);
+    for (int it = 0; it < CHEB_POWER_ITS; ++it) {
+      int sb = 0;
+      NG_TRY((spmv_with_halo<false, false>(h, x, y, false, &sb)));
+      k_cheb_power<<<vb, 256, 0, h->stream>>>(n, h->dDinv, x, y, h->dPartials);
+      NG_TRY(finish_reduction(h, 3, vb));
+      NG_TRY(fetch(3));
+      lambda = pin[0] / pin[1];
+      norm = std::sqrt(pin[2]);
+      if (norm == 0.0) { lambda = 0.0; break; }
+      k_div_copy<<<vb, 256, 0, h->stream>>>(n, y, norm, x);
+    }
+  }
+  NG_HIP(hipGetLastError());
+  h->chebLambdaMax = lambda;
+  return NALU_GPU_OK;
+}
+
+// x = Cheb(r); x must be a column-space vector (it is multiplied by A); uses dT and dChebV
+int apply_cheb(nalu_gpu_linsys *h, const double *r, double *x, bool useDone)
+{
+  const long long n = h->nOwned;
+  const int vb = vec_grid(n);
+  const SolverScalars *sc = useDone ? h->dScal : nullptr;
+  const double lambdaMax = h->chebLambdaMax;
+  const double alpha = lambdaMax / CHEB_RATIO, beta = CHEB_BOOST * lambdaMax;
+  const double delta = 2.0 / (beta - alpha), theta = (beta + alpha) / 2.0, s1 = theta * delta;
+  double *w = h->dT, *v = h->dChebV;
+  k_cheb_first<<<vb, 256, 0, h->stream>>>(n, sc, 1.0 / theta, h->dDinv, r, w, x);
+  double rhok = 1.0 / s1;
+  for (int deg = 1; deg < CHEB_DEGREE; ++deg) {
+    int sb = 0;
+    NG_TRY((spmv_with_halo<false, false>(h, x, v, useDone, &sb)));
+    const double rhokp1 = 1.0 / (2.0 * s1 - rhok);
+    const double d1 = rhokp1 * rhok, d2 = 2.0 * rhokp1 * delta;
+    rhok = rhokp1;
+    k_cheb_step<<<vb, 256, 0, h->stream>>>(n, sc, d1, d2, h->dDinv, r, v, w, x);
+  }
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+// z = M^-1 r for the preconditioners that are not a diagonal scaling
+int apply_general(nalu_gpu_linsys *h, int precond, const double *r, double *z, bool useDone)
+{
+  return precond == NALU_GPU_PRECOND_CHEBYSHEV ? apply_cheb(h, r, z, useDone) : apply_sgs(h, r, z, useDone);
+}
+
 // ------------------------------------------------------------------------- CG
 __global__ __launch_bounds__(256) void k_cg_init(long long n, const double *__restrict__ b,
                                                   const double *__restrict__ dinv,
@@ -720,14 +861,14 @@ __global__ __launch_bounds__(256) void k_pcg_p(long long n, const SolverScalars 
   GRID_STRIDE(i, n) p[i] = first ? z[i] : z[i] + beta * p[i];
 }
 
-int solve_cg_sgs(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEvery)
+int solve_cg_general(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEvery)
 {
   const long long n = h->nOwned;
   const int vb = vec_grid(n);
   double *z = h->dW;
   k_pcg_init<<<vb, 256, 0, h->stream>>>(n, h->dRhs, h->dX, h->dR, h->dPartials);
   NG_TRY(reduce_partials(h, 1, vb, 1));  // r.r -> reduce[1]
-  NG_TRY(apply_sgs(h, h->dR, z, false));
+  NG_TRY(apply_general(h, cfg->precond, h->dR, z, false));
   k_dot<<<vb, 256, 0, h->stream>>>(n, h->dR, z, h->dPartials);
   NG_TRY(reduce_partials(h, 1, vb, 0));  // r.z -> reduce[0]
   NG_TRY(allreduce(h, 2));
@@ -746,7 +887,7 @@ int solve_cg_sgs(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int chec
     k_pcg_update<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dP, h->dQ, h->dX, h->dR, h->dPartials);
     NG_TRY(finish_reduction(h, 1, vb));
     k_pcg_scal_test<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist);
-    NG_TRY(apply_sgs(h, h->dR, z, true));
+    NG_TRY(apply_general(h, cfg->precond, h->dR, z, true));
     k_dot_done<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dR, z, h->dPartials);
     NG_TRY(finish_reduction(h, 1, vb));
     k_pcg_scal_beta<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
@@ -776,7 +917,7 @@ __global__ __launch_bounds__(256) void k_gm_combine(long long n, const SolverSca
 
 int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEvery)
 {
-  const bool sgs = cfg->precond == NALU_GPU_PRECOND_SGS;
+  const bool sgs = cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV;
   const long long n = h->nOwned, ld = h->nCols;
   const int m = cfg->kspace;
   NG_REQUIRE(m >= 1 && m + 1 <= REDUCE_CAP, NALU_GPU_EINVAL, "kspace must be in [1,%d]", REDUCE_CAP - 1);
@@ -822,7 +963,7 @@ int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int check
       double *vj = h->dV + (size_t)j * ld;
       int sb = 0;
       if (sgs) {  // w = A (M^-1 v_j)
-        NG_TRY(apply_sgs(h, vj, h->dP, true));
+        NG_TRY(apply_general(h, cfg->precond, vj, h->dP, true));
         NG_TRY((spmv_with_halo<false, false>(h, h->dP, h->dW, true, &sb)));
       } else {
         NG_TRY((spmv_with_halo<false, true>(h, vj, h->dW, true, &sb)));
@@ -852,7 +993,7 @@ int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int check
     k_gm_solve_y<<<1, 1, 0, h->stream>>>(h->dScal, h->dH, h->dG, h->dY, m);
     if (sgs) {  // x += M^-1 (V y)
       k_gm_combine<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dV, ld, h->dY, h->dR);
-      NG_TRY(apply_sgs(h, h->dR, h->dP, false));
+      NG_TRY(apply_general(h, cfg->precond, h->dR, h->dP, false));
       k_axpy<<<vb, 256, 0, h->stream>>>(n, 1.0, h->dP, h->dX);
     } else {
       k_gm_update_x<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dV, ld, h->dY, h->dDinv, h->dX);
@@ -921,9 +1062,9 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
   NG_REQUIRE(cfg->method == NALU_GPU_METHOD_CG || cfg->method == NALU_GPU_METHOD_GMRES,
              NALU_GPU_EUNSUPPORTED, "solver method %d (supported: cg, gmres)", cfg->method);
   NG_REQUIRE(cfg->precond == NALU_GPU_PRECOND_NONE || cfg->precond == NALU_GPU_PRECOND_JACOBI ||
-                 cfg->precond == NALU_GPU_PRECOND_SGS,
+                 cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV,
              NALU_GPU_EUNSUPPORTED,
-             "preconditioner %d (supported: none, jacobi, sgs; the reference throws on unknown "
+             "preconditioner %d (supported: none, jacobi, sgs, chebyshev; the reference throws on unknown "
              "names, src/LinearSolverConfig.C:97-99)", cfg->precond);
   NG_REQUIRE(cfg->max_iterations >= 0 && cfg->tolerance >= 0.0, NALU_GPU_EINVAL, "bad solver limits");
   NG_TRY(materialize_zero(h));
@@ -940,13 +1081,15 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
   if (cfg->precond == NALU_GPU_PRECOND_SGS) NG_TRY(ensure_sgs_levels(h));
   NG_HIP(hipGetLastError());
   NG_TRY(halo_exchange(h, h->dDinv));
+  if (cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV) NG_TRY(cheb_compute(h));
   timer_end(h, NALU_GPU_T_PRECOND);
   NG_HIP(hipStreamSynchronize(h->stream));
   const auto t1 = std::chrono::steady_clock::now();
 
   timer_begin(h, NALU_GPU_T_SOLVE);
-  if (cfg->method == NALU_GPU_METHOD_CG && cfg->precond == NALU_GPU_PRECOND_SGS)
-    NG_TRY(solve_cg_sgs(h, cfg, checkEvery));
+  if (cfg->method == NALU_GPU_METHOD_CG &&
+      (cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV))
+    NG_TRY(solve_cg_general(h, cfg, checkEvery));
   else if (cfg->method == NALU_GPU_METHOD_CG) NG_TRY(solve_cg(h, cfg, checkEvery));
   else NG_TRY(solve_gmres(h, cfg, checkEvery));
   timer_end(h, NALU_GPU_T_SOLVE);

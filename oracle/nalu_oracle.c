@@ -989,12 +989,85 @@ static double dot(const double *a, const double *b, int64_t n)
 /* Ifpack2 RELAXATION applied to a zero starting solution, 1 sweep, damping 1
  * (src/LinearSolverConfig.C:71-85; Ifpack2 itself is not in the tree):
  *   Jacobi: z = D^-1 r ;  SGS: z = (D+U)^-1 D (D+L)^-1 r. */
+/* Chebyshev polynomial preconditioner.  The reference itself offers none at the Ifpack2
+ * level (src/LinearSolverConfig.C:71-99); BASELINE's north star asks for one and SURVEY.md
+ * fixes its parameters from the MueLu smoother block reg_tests/xml/milestone.xml:5-12:
+ * degree 2, eigenvalue ratio 20, 15 power iterations, zero starting solution.  Algorithm:
+ * Ifpack2::Details::Chebyshev (ifpackApplyImpl + powerMethod; Trilinos, not in the tree,
+ * restated from its published form: PARITY UNPINNED), on D^-1 A, boost factor 1.1.  Ifpack2
+ * starts the power method from a random vector; here the start vector is a fixed hash of
+ * the global node id so that runs are reproducible on any rank count. */
+#define ORC_CHEB_DEGREE 2
+#define ORC_CHEB_RATIO 20.0
+#define ORC_CHEB_POWER_ITS 15
+#define ORC_CHEB_BOOST 1.1
+static double g_cheb_lambda_max = 0.0;
+
+double orc_cheb_start_value(int64_t gid)
+{
+  uint32_t h = (uint32_t)gid * 2654435761u;
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return (double)h / 4294967296.0 * 2.0 - 1.0;
+}
+
+static double dot(const double *a, const double *b, int64_t n);
+
+static double cheb_power_method(const orc_linsys *ls, const double *dinv)
+{
+  const int64_t n = ls->ownedGraph->nrows;
+  double *x = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+  double *y = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+  for (int64_t i = 0; i < n; ++i) x[i] = orc_cheb_start_value(g_gids ? g_gids[i] : i + 1);
+  double lambda = 0.0;
+  double norm = orc_norm2(x, n);
+  if (norm != 0.0) {
+    for (int64_t i = 0; i < n; ++i) x[i] = x[i] / norm;
+    for (int it = 0; it < ORC_CHEB_POWER_ITS; ++it) {
+      orc_spmv(ls, x, y);
+      for (int64_t i = 0; i < n; ++i) y[i] = dinv[i] * y[i];
+      const double top = dot(y, x, n), bot = dot(x, x, n);
+      lambda = top / bot;
+      norm = orc_norm2(y, n);
+      if (norm == 0.0) { lambda = 0.0; break; }
+      for (int64_t i = 0; i < n; ++i) x[i] = y[i] / norm;
+    }
+  }
+  free(x); free(y);
+  return lambda;
+}
+
+static void cheb_apply(const orc_linsys *ls, const double *dinv, const double *r, double *x)
+{
+  const int64_t n = ls->ownedGraph->nrows;
+  const double lambdaMax = g_cheb_lambda_max;
+  const double alpha = lambdaMax / ORC_CHEB_RATIO, beta = ORC_CHEB_BOOST * lambdaMax;
+  const double delta = 2.0 / (beta - alpha), theta = (beta + alpha) / 2.0, s1 = theta * delta;
+  const double oneOverTheta = 1.0 / theta;
+  double *w = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+  double *v = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+  for (int64_t i = 0; i < n; ++i) { w[i] = oneOverTheta * (dinv[i] * r[i]); x[i] = w[i]; }
+  double rhok = 1.0 / s1;
+  for (int deg = 1; deg < ORC_CHEB_DEGREE; ++deg) {
+    orc_spmv(ls, x, v);
+    const double rhokp1 = 1.0 / (2.0 * s1 - rhok);
+    const double dtemp1 = rhokp1 * rhok, dtemp2 = 2.0 * rhokp1 * delta;
+    rhok = rhokp1;
+    for (int64_t i = 0; i < n; ++i) {
+      w[i] = dtemp1 * w[i] + dtemp2 * (dinv[i] * (r[i] - v[i]));
+      x[i] = x[i] + w[i];
+    }
+  }
+  free(w); free(v);
+}
+
 static void apply_precond(const orc_linsys *ls, int precond, const double *dinv,
                           const double *r, double *z, double *tmp)
 {
   const orc_graph *g = ls->ownedGraph;
   const int64_t n = g->nrows;
-  if (precond == 0) {
+  if (precond == 3) {
+    cheb_apply(ls, dinv, r, z);
+  } else if (precond == 0) {
     memcpy(z, r, sizeof(double) * (size_t)n);
   } else if (precond == 1) {
 #pragma omp parallel for schedule(static)
@@ -1040,6 +1113,7 @@ int orc_solve(orc_linsys *ls, const orc_solver_config *cfg, double *finalResidNr
     dinv[i] = 1.0 / d;
   }
   double *tmp = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+  if (cfg->precond == 3) g_cheb_lambda_max = cheb_power_method(ls, dinv); /* compute() */
   for (int64_t i = 0; i < n; ++i) x[i] = 0.0; /* zeroSystem: x0 = 0 */
 
   const double r0 = orc_norm2(b, n);

@@ -175,7 +175,8 @@ void orc_project_nodal_velocity(int64_t nnodes, double dt, double gamma1, const 
 void orc_spmv(const orc_linsys *ls, const double *x, double *y);
 typedef struct {
   int method;  /* 0 = cg, 1 = gmres */
-  int precond; /* 0 = none, 1 = jacobi (src/LinearSolverConfig.C:81-85), 2 = sgs (:71-75) */
+  int precond; /* 0 = none, 1 = jacobi (src/LinearSolverConfig.C:81-85), 2 = sgs (:71-75),
+                  3 = chebyshev (not a reference option: see cheb_apply in nalu_oracle.c) */
   double tolerance;
   int max_iterations;
   int kspace;

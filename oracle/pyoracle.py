@@ -64,7 +64,7 @@ class SolverConfig(C.Structure):
 
 
 METHODS = {"cg": 0, "gmres": 1}
-PRECONDS = {"none": 0, "jacobi": 1, "default": 1, "sgs": 2}
+PRECONDS = {"none": 0, "jacobi": 1, "default": 1, "sgs": 2, "chebyshev": 3}
 
 
 def _bind(lib):

@@ -207,6 +207,9 @@ def _pin(ls, g, c, node=0):
     ("gmres", "sgs", dict(tolerance=1e-10, max_iterations=200, kspace=50)),
     ("gmres", "sgs", dict(tolerance=1e-6, max_iterations=40, kspace=5)),
     ("cg", "sgs", dict(tolerance=1e-10, max_iterations=300)),
+    # Chebyshev(2, ratio 20, 15 power iterations): Ifpack2's algorithm restated (parity unpinned)
+    ("cg", "chebyshev", dict(tolerance=1e-10, max_iterations=300)),
+    ("gmres", "chebyshev", dict(tolerance=1e-10, max_iterations=200, kspace=50)),
 ])
 def test_solve_history_and_fields(G, torch, oracle, method, precond, kw):
     """config 2 in small: continuity assembly + pinned node, Jacobi-CG / GMRES."""
@@ -254,7 +257,7 @@ def test_solve_zero_rhs_and_reuse(G, torch, oracle):
         assert g.linearSolveIterations == 0 and g.linearResidual == 0.0
         assert not g.solution().any()
     with pytest.raises(G.NaluGpuError):
-        g.solve(G.LinearSolverConfig(method="cg", preconditioner="chebyshev"))
+        g.solve(G.LinearSolverConfig(method="cg", preconditioner="ilut"))
     with pytest.raises(RuntimeError):
         G.LinearSolverConfig(preconditioner="bogus")
 
