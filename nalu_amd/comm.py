@@ -62,11 +62,26 @@ class TorchComm:
         # gloo (tests: several ranks on one GPU) has no device send/recv: stage through the host
         self.stage = dist.get_backend(group) == "gloo" and str(device).startswith("cuda")
         self._recv_host = None
+        # the P2P op list and the reduce-buffer views are built once: the callbacks run two to
+        # three times per Krylov iteration and their host cost must stay below the kernels'
+        self._ops = None if self.stage else self._make_ops(self.send, self.recv)
+        self._views = {}
         self._ar = L.ALLREDUCE_FN(self._allreduce)
         self._xb = L.EXCHANGE_FN(self._exchange_begin)
         self._xe = L.EXCHANGE_FN(self._exchange_end)
         self.struct = L.Comm(None, self._ar, self._xb, self._xe)
         linsys.set_comm(self.struct)
+
+    def _make_ops(self, send, recv):
+        ops = []
+        for n, p in enumerate(self.neighbors):
+            a, b = self.so[n], self.so[n + 1]
+            if b > a:
+                ops.append(dist.P2POp(dist.isend, send[a:b], p, group=self.group))
+            a, b = self.ro[n], self.ro[n + 1]
+            if b > a:
+                ops.append(dist.P2POp(dist.irecv, recv[a:b], p, group=self.group))
+        return ops
 
     # callbacks must never raise through ctypes: record and return non-zero
     def _allreduce(self, ctx, count, stream):
@@ -76,7 +91,10 @@ class TorchComm:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
                 self.reduce[:count].copy_(t)
             else:
-                dist.all_reduce(self.reduce[:count], op=dist.ReduceOp.SUM, group=self.group)
+                v = self._views.get(count)
+                if v is None:
+                    v = self._views[count] = self.reduce[:count]
+                dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
             return 0
         except Exception as e:  # pragma: no cover
             self.errors.append(repr(e))
@@ -84,11 +102,12 @@ class TorchComm:
 
     def _exchange_begin(self, ctx, stream):
         try:
-            send, recv = self.send, self.recv
             if self.stage:
                 send = self.send.cpu()
                 recv = self._recv_host = torch.empty(self.recv.shape, dtype=torch.float64)
-            self.pending = exchange_halo(send, recv, self.neighbors, self.so, self.ro, self.group)
+                self.pending = exchange_halo(send, recv, self.neighbors, self.so, self.ro, self.group)
+            else:
+                self.pending = dist.batch_isend_irecv(self._ops) if self._ops else []
             return 0
         except Exception as e:  # pragma: no cover
             self.errors.append(repr(e))
