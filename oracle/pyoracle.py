@@ -342,6 +342,20 @@ def project_nodal_velocity(dt, gamma1, dpdx_new, dpdx_old, rho, vel, projected=N
     return u
 
 
+def set_values(ls, vals):
+    """overwrite the owned CSR values (test set-up: same numbers on both sides)"""
+    nnz = len(ls.owned_csr()[2])
+    v = f64(vals)
+    assert len(v) == nnz
+    C.memmove(ls.p.contents.ownedVals, v.ctypes.data, 8 * nnz)
+
+
+def set_rhs(ls, b):
+    b = f64(b)
+    assert len(b) == ls.n_owned * ls.num_dof
+    C.memmove(ls.p.contents.ownedRhs, b.ctypes.data, 8 * len(b))
+
+
 # --------------------------------------------- reference F77 kernels (_ref)
 def ref_geom():
     """The reference's own hex_scs_det / hex_scv_det, compiled by oracle/Makefile from

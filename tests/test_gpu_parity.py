@@ -497,3 +497,44 @@ def test_irregular_node_numbering(G, torch, oracle, kind):
                                  max_iterations=150, kspace=40))
     assert g.linearSolveIterations == ref["iters"]
     assert np.abs(g.history - ref["history"]).max() <= TOL_SOLVE
+
+
+def test_element_graph_27_point_rows(G, torch, oracle):
+    """Hex8 element graph (rows of up to 27 entries: SpMV chunks of 8 + remainder, SGS levels
+    and column offsets on a denser stencil) with random diagonally dominant values."""
+    m = oracle.BoxMesh(7, 6, 5)
+    n = m.nnodes
+    ls = oracle.LinSys(1, n)
+    ls.add_connections(m.hex_nodes)
+    ls.finalize()
+    ls.zero()
+    g = G.GpuLinearSystem()
+    g.beginLinearSystemConstruction(n)
+    g.buildElemToNodeGraph(m.hex_nodes)
+    g.finalizeLinearSystem()
+    rp, ci = g.graph()
+    orp, oci, _ = ls.owned_csr()
+    assert np.array_equal(rp, orp) and np.array_equal(ci, oci) and np.diff(rp).max() == 27
+    rs = np.random.RandomState(2)
+    v = rs.uniform(-1, 1, len(ci))
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    rowsum = np.bincount(rows, np.abs(v), n)
+    v[ci == rows] = rowsum + 1.0  # strictly diagonally dominant
+    # values are set directly on both sides: the CSR order is identical
+    oracle.set_values(ls, v)
+    g.set_matrix_values(v)
+    b = rs.uniform(-1, 1, n)
+    oracle.set_rhs(ls, b)
+    g.set_rhs(b)
+    x = rs.uniform(-1, 1, n)
+    y = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    g.spmv(torch.as_tensor(x, device="cuda:0"), y)
+    g.synchronize()
+    assert np.array_equal(y.cpu().numpy(), ls.spmv(x))
+    for method, pc in (("gmres", "jacobi"), ("gmres", "sgs"), ("gmres", "chebyshev"), ("cg", "sgs")):
+        kw = dict(tolerance=1e-11, max_iterations=120, kspace=40)
+        ref = ls.solve(method, pc, **kw)
+        g.solve(G.LinearSolverConfig(method=method, preconditioner=pc, **kw))
+        assert g.linearSolveIterations == ref["iters"], (method, pc)
+        assert np.abs(g.history - ref["history"]).max() <= TOL_SOLVE, (method, pc)
+        assert rel_err(g.solution(), ref["x"]) <= 1e-9
