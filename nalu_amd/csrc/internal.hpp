@@ -65,6 +65,7 @@ constexpr int PARTIAL_SLOTS = 8;  // simultaneous reductions per kernel
 struct SolverScalars {
   double rz, rr0, r0norm, alpha, beta, tol, hn;
   int iter, done, j, maxIter, histCap, pad;
+  double *alphaHist;  // CG: alpha of every iteration (the x update is applied in batches)
 };
 
 }  // namespace nalu_gpu
@@ -132,6 +133,9 @@ struct nalu_gpu_linsys {
   double *dReduce = nullptr;    // REDUCE_CAP
   nalu_gpu::SolverScalars *dScal = nullptr;
   double *dHist = nullptr;
+  double *dAlphaHist = nullptr;  // histCap
+  double *dPRing = nullptr;      // CG direction ring: pRingM vectors of nCols
+  int pRingM = 0;
   int histCap = 0;
   double *dH = nullptr, *dCs = nullptr, *dSn = nullptr, *dG = nullptr, *dY = nullptr;
   int hCap = 0;

@@ -52,6 +52,7 @@ __device__ __forceinline__ void cg_scal_a(SolverScalars *sc, const double *red)
 {
   if (sc->done) return;
   sc->alpha = sc->rz / red[0];
+  if (sc->alphaHist && sc->iter < sc->histCap) sc->alphaHist[sc->iter] = sc->alpha;
 }
 
 __device__ __forceinline__ void cg_scal_b(SolverScalars *sc, const double *red, double *hist)
@@ -513,8 +514,9 @@ __global__ __launch_bounds__(256) void k_cg_init(long long n, const double *__re
 }
 
 __global__ void k_cg_scal_init(SolverScalars *sc, const double *red, double *hist, double tol,
-                               int maxIter, int histCap)
+                               int maxIter, int histCap, double *alphaHist = nullptr)
 {
+  sc->alphaHist = alphaHist;
   sc->rz = red[0];
   sc->rr0 = red[1];
   sc->r0norm = sqrt(red[1]);
@@ -557,24 +559,33 @@ __global__ void k_cg_scal_b(SolverScalars *sc, const double *red, double *hist)
   cg_scal_b(sc, red, hist);
 }
 
-// x += alpha p_old ; p = z + beta p_old.  `it` is the host's iteration index: in the iteration
-// that set the done flag (sc->iter == it + 1) only x is finished; later launches return.
+// p_new = z + beta p_old, written to the next slot of the direction ring
 __global__ __launch_bounds__(256) void k_cg_p(long long n, const SolverScalars *__restrict__ sc,
-                                               int it, const double *__restrict__ dinv,
-                                               const double *__restrict__ r, double *__restrict__ x,
-                                               double *__restrict__ p)
+                                               const double *__restrict__ dinv,
+                                               const double *__restrict__ r,
+                                               const double *__restrict__ pOld, double *__restrict__ pNew)
 {
-  const double alpha = sc->alpha;
-  if (sc->done) {
-    if (sc->iter != it + 1) return;
-    GRID_STRIDE(i, n) x[i] += alpha * p[i];
-    return;
-  }
+  if (sc->done) return;
   const double beta = sc->beta;
+  GRID_STRIDE(i, n) pNew[i] = ldnt(dinv + i) * ldnt(r + i) + beta * ldnt(pOld + i);
+}
+
+// The solution update x += alpha_k p_k is applied in batches: the directions of up to M
+// iterations stay in a ring and x is read and written once per batch instead of once per
+// iteration.  The terms are added in iteration order, so x is bit-identical to the
+// per-iteration update.  k0 = first iteration of the batch; the count comes from the device
+// iteration counter (iterations that completed, including the one that set the done flag).
+__global__ __launch_bounds__(256) void k_cg_flush_x(long long n, const SolverScalars *__restrict__ sc,
+                                                     const double *__restrict__ ring, long long ld,
+                                                     int M, int k0, double *__restrict__ x)
+{
+  const int cnt = min(M, sc->iter - k0);
+  if (cnt <= 0) return;
+  const double *ah = sc->alphaHist;
   GRID_STRIDE(i, n) {
-    const double pi = ldnt(p + i);
-    x[i] = ldnt(x + i) + alpha * pi;
-    p[i] = ldnt(dinv + i) * ldnt(r + i) + beta * pi;
+    double xi = ldnt(x + i);
+    for (int k = k0; k < k0 + cnt; ++k) xi += ah[k] * ldnt(ring + (long long)(k % M) * ld + i);
+    x[i] = xi;
   }
 }
 
@@ -748,7 +759,9 @@ int ensure_hist(nalu_gpu_linsys *h, int cap)
   if (cap <= h->histCap) return NALU_GPU_OK;
   NG_HIP(hipStreamSynchronize(h->stream));
   if (h->dHist) (void)hipFree(h->dHist);
+  if (h->dAlphaHist) (void)hipFree(h->dAlphaHist);
   NG_HIP(hipMalloc(&h->dHist, sizeof(double) * (size_t)cap));
+  NG_HIP(hipMalloc(&h->dAlphaHist, sizeof(double) * (size_t)cap));
   h->histCap = cap;
   return NALU_GPU_OK;
 }
@@ -761,15 +774,29 @@ int solve_cg(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEve
   // thread streams a few % faster than a 2048-workgroup grid-stride loop (scripts/membench)
   static const int pbDiv = getenv("NG_P_DIV") ? atoi(getenv("NG_P_DIV")) : 1;
   const int pb = (int)std::max<long long>(1, std::min<long long>((n + 256LL * pbDiv - 1) / (256LL * pbDiv), 1 << 22));
-  k_cg_init<<<vb, 256, 0, h->stream>>>(n, h->dRhs, h->dDinv, h->dX, h->dR, h->dP, h->dPartials);
+  // direction ring (see k_cg_flush_x): as many vectors as fit a modest share of the HBM
+  const long long ld = std::max(h->nCols, 1);
+  int M = 16;
+  while (M > 2 && (double)M * ld * sizeof(double) > 24e9) M /= 2;
+  if (h->pRingM != M) {
+    NG_HIP(hipStreamSynchronize(h->stream));
+    if (h->dPRing) (void)hipFree(h->dPRing);
+    h->dPRing = nullptr;
+    NG_HIP(hipMalloc(&h->dPRing, sizeof(double) * (size_t)M * (size_t)ld));
+    NG_HIP(hipMemsetAsync(h->dPRing, 0, sizeof(double) * (size_t)M * (size_t)ld, h->stream));
+    h->pRingM = M;
+  }
+  auto slot = [&](int it) { return h->dPRing + (size_t)(it % M) * (size_t)ld; };
+  k_cg_init<<<vb, 256, 0, h->stream>>>(n, h->dRhs, h->dDinv, h->dX, h->dR, slot(0), h->dPartials);
   NG_HIP(hipGetLastError());
   NG_TRY(finish_reduction(h, 2, vb));
   k_cg_scal_init<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist, cfg->tolerance,
-                                         cfg->max_iterations, h->histCap);
+                                         cfg->max_iterations, h->histCap, h->dAlphaHist);
   SolverScalars sc;
+  int flushed = 0;  // x holds the updates of the iterations before this one
   for (int it = 0; it < cfg->max_iterations; ++it) {
     int sb = 0;
-    NG_TRY((spmv_with_halo<true, false>(h, h->dP, h->dQ, true, &sb)));
+    NG_TRY((spmv_with_halo<true, false>(h, slot(it), h->dQ, true, &sb)));
     const double *pp = nullptr;
     NG_TRY(prereduce_slices(h, &sb, &pp, true));
     if (h->hasComm) {
@@ -786,13 +813,19 @@ int solve_cg(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEve
       k_reduce_partials<EPI_CG_B><<<1, RED_T, 0, h->stream>>>(h->dPartials, vb, 2, h->dReduce,
                                                             h->dScal, h->dHist);
     }
-    k_cg_p<<<pb, 256, 0, h->stream>>>(n, h->dScal, it, h->dDinv, h->dR, h->dX, h->dP);
+    if ((it + 1) % M == 0) {  // the next direction overwrites the oldest one of this batch
+      k_cg_flush_x<<<pb, 256, 0, h->stream>>>(n, h->dScal, h->dPRing, ld, M, flushed, h->dX);
+      flushed = it + 1;
+    }
+    k_cg_p<<<pb, 256, 0, h->stream>>>(n, h->dScal, h->dDinv, h->dR, slot(it), slot(it + 1));
     NG_HIP(hipGetLastError());
     if ((it + 1) % checkEvery == 0 && it + 1 < cfg->max_iterations) {
       NG_TRY(read_scalars(h, &sc));
       if (sc.done) break;
     }
   }
+  k_cg_flush_x<<<pb, 256, 0, h->stream>>>(n, h->dScal, h->dPRing, ld, M, flushed, h->dX);
+  NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
 }
 
