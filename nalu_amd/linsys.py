@@ -16,10 +16,11 @@ def _ptr(t):
 
 
 def _vec3(t):
-    """(3, n) contiguous fp64 device tensor -> nalu_gpu_vec3 of its rows (SoA)"""
-    assert t.dim() == 2 and t.shape[0] == 3 and t.is_contiguous() and t.dtype.is_floating_point
+    """(3, n) fp64 device tensor with unit-stride rows -> nalu_gpu_vec3 of its rows (SoA);
+    the rows need not be adjacent (a padded row pitch is fine)"""
+    assert t.dim() == 2 and t.shape[0] == 3 and t.stride(1) == 1 and t.dtype.is_floating_point
     assert t.element_size() == 8
-    n = t.shape[1] * 8
+    n = t.stride(0) * 8
     p = t.data_ptr()
     return L.Vec3(p, p + n, p + 2 * n)
 
@@ -229,7 +230,7 @@ class GpuLinearSystem:
     def _check_fields(self, *node_fields, edge_area=None, edge_scalar=None):
         # host-side shape checks: the kernels index n_cols nodes and n_edges edges
         for t in node_fields:
-            assert t.shape[-1] >= self.n_cols and t.is_contiguous() and t.element_size() == 8, \
+            assert t.shape[-1] >= self.n_cols and t.stride(-1) == 1 and t.element_size() == 8, \
                 "nodal field smaller than the local node count"
         ne = getattr(self, "n_edges", 0)
         if edge_area is not None:
