@@ -693,6 +693,192 @@ __global__ __launch_bounds__(256) void k_gm_update(long long n, const SolverScal
   if (wantNorm) block_sums<1>(acc, partials, 1);
 }
 
+// out[t] = fixed-order sum of the nb partials of vector t (one workgroup per vector)
+__global__ __launch_bounds__(256) void k_gm_reduce_cols(const double *__restrict__ partials, int nb,
+                                                         double *__restrict__ out,
+                                                         const SolverScalars *__restrict__ sc)
+{
+  if (sc->done) return;
+  __shared__ double s[256];
+  const double *p = partials + (size_t)blockIdx.x * nb;
+  double v = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) v += p[i];
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = s[0];
+}
+
+// Iterated classical Gram-Schmidt with three sweeps over the basis instead of four:
+//   k_gm_dots_all : h = V^T w for all J vectors, w read once (not once per 8 vectors);
+//   k_gm_upd_dots : w -= V h, then h2 = V^T w of the UPDATED w, with V read once -- a tile of V is
+//                   staged in LDS between the two uses;
+//   k_gm_update   : w -= V h2 and ||w||^2 (above).
+// In both kernels wave v of a workgroup owns the vectors t = v, v+4, ... and keeps one
+// accumulator per vector in registers over the whole grid-stride loop: one partial per
+// (vector, workgroup), no cross-wave reduction; fixed grid and fixed order: deterministic.
+constexpr int GM_TILE = 128;
+constexpr int GM_MAXV = 52;   // vectors per pass (kspace 50 is the reference's default)
+constexpr int GM_GRID = 768;  // persistent grid: three workgroups per CU
+__global__ __launch_bounds__(256, 3) void k_gm_dots_all(long long n, const SolverScalars *__restrict__ sc,
+                                                         const double *__restrict__ V, long long ld, int J,
+                                                         const double *__restrict__ w,
+                                                         double *__restrict__ partials)
+{
+  if (sc->done) return;
+  constexpr int NA = (GM_MAXV + 3) / 4;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double acc[NA];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) acc[q] = 0.0;
+  const long long ntiles = (n + GM_TILE - 1) / GM_TILE;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long e0 = tile * GM_TILE;
+    const bool in0 = e0 + lane < n, in1 = e0 + 64 + lane < n;
+    const double w0 = in0 ? w[e0 + lane] : 0.0, w1 = in1 ? w[e0 + 64 + lane] : 0.0;
+    double a[NA], b[NA];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int t = wv + 4 * q;
+      a[q] = (t < J && in0) ? ldnt(V + (long long)t * ld + e0 + lane) : 0.0;
+      b[q] = (t < J && in1) ? ldnt(V + (long long)t * ld + e0 + 64 + lane) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      acc[q] += a[q] * w0;
+      acc[q] += b[q] * w1;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int t = wv + 4 * q;
+    if (t < J) {  // uniform per wave
+      const double r = wave_sum(acc[q]);
+      if (lane == 0) partials[(size_t)t * gridDim.x + blockIdx.x] = r;
+    }
+  }
+}
+
+// Tile = 128 * MULT elements, J <= GM_MAXV / MULT vectors (small J takes large tiles so that
+// enough bytes are in flight).  Thread (half, e) carries the vectors t = half, half+2, ... of
+// the elements e + 128 m: it fetches the NEXT tile into registers while the current one is
+// worked on, forms its half of the update sum_t h_t V_t from those registers (t ascending; the
+// two halves are added through LDS: w - (even + odd)) and stages the values in LDS for the
+// dot products with the updated w.  LDS: (J + 3) * 128 * MULT doubles.
+template <int MULT>
+__global__ __launch_bounds__(256, 3) void k_gm_upd_dots(long long n, const SolverScalars *__restrict__ sc,
+                                                         const double *__restrict__ V, long long ld, int J,
+                                                         const double *__restrict__ hred,
+                                                         double *__restrict__ w, double *__restrict__ Hcol,
+                                                         int first, double *__restrict__ partials)
+{
+  if (sc->done) return;
+  constexpr int TE = GM_TILE * MULT;
+  constexpr int JM = GM_MAXV / MULT;
+  constexpr int NQ = (JM + 1) / 2;  // vectors per half
+  constexpr int NA = (JM + 3) / 4;  // vectors per wave in the dot phase
+  extern __shared__ double lds[];   // [J][TE] tile of V | [2][TE] half sums | [TE] updated w
+  double *ldsP = lds + (size_t)J * TE, *ldsW = ldsP + 2 * TE;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, e = tid & (GM_TILE - 1);
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform: scalar addresses
+  double acc[NA], hq[NQ];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) acc[q] = 0.0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) hq[q] = (half + 2 * q < J) ? hred[half + 2 * q] : 0.0;
+  const long long ntiles = (n + TE - 1) / TE;
+  double pre[NQ][MULT], wpre[MULT];
+  auto prefetch = [&](long long tile) {
+    // uniform 64-bit base per vector + one 32-bit lane offset (n < 2^29, checked by the host)
+    const double *vb = V + (long long)half * ld;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+      for (int m = 0; m < MULT; ++m) {
+        const unsigned off = (unsigned)(tile * TE) + (unsigned)(m * GM_TILE + e);
+        pre[q][m] = (tile < ntiles && off < (unsigned)n && half + 2 * q < J) ? ldnt(vb + off) : 0.0;
+      }
+      vb += 2 * ld;
+    }
+#pragma unroll
+    for (int m = 0; m < MULT; ++m) {
+      const unsigned off = (unsigned)(tile * TE) + (unsigned)(m * GM_TILE + e);
+      wpre[m] = (tile < ntiles && off < (unsigned)n) ? w[off] : 0.0;
+    }
+  };
+  prefetch(blockIdx.x);
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    double wn[MULT];
+#pragma unroll
+    for (int m = 0; m < MULT; ++m) {
+      double sum = 0.0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (half + 2 * q < J) lds[(half + 2 * q) * TE + m * GM_TILE + e] = pre[q][m];
+        sum += hq[q] * pre[q][m];
+      }
+      ldsP[half * TE + m * GM_TILE + e] = sum;
+      wn[m] = wpre[m];
+    }
+    __syncthreads();
+    const long long e0 = tile * TE;
+    prefetch(tile + gridDim.x);
+    if (half == 0) {
+#pragma unroll
+      for (int m = 0; m < MULT; ++m) {
+        const int el = m * GM_TILE + e;
+        wn[m] -= ldsP[el] + ldsP[TE + el];
+        if (e0 + el < n) w[e0 + el] = wn[m];
+        ldsW[el] = wn[m];
+      }
+    }
+    __syncthreads();
+    double wl[2 * MULT];
+#pragma unroll
+    for (int m = 0; m < 2 * MULT; ++m) wl[m] = ldsW[m * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int t = wv + 4 * q;
+      if (t < J) {
+#pragma unroll
+        for (int m = 0; m < 2 * MULT; ++m) acc[q] += lds[t * TE + m * 64 + lane] * wl[m];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int t = wv + 4 * q;
+    if (t < J) {  // uniform per wave
+      const double r = wave_sum(acc[q]);
+      if (lane == 0) partials[(size_t)t * gridDim.x + blockIdx.x] = r;
+    }
+  }
+  if (blockIdx.x == 0)
+    for (int t = tid; t < J; t += blockDim.x) Hcol[t] = first ? hred[t] : Hcol[t] + hred[t];
+}
+
+template <int MULT>
+void launch_upd_dots(nalu_gpu_linsys *h, long long n, long long ld, int J, double *Hcol)
+{
+  static const bool ldsOptIn = [] {  // more than 48 KiB of dynamic LDS
+    (void)hipFuncSetAttribute((const void *)k_gm_upd_dots<MULT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              65536);
+    (void)hipGetLastError();
+    return true;
+  }();
+  (void)ldsOptIn;
+  constexpr int TE = GM_TILE * MULT;
+  const int gb = (int)std::min<long long>((n + TE - 1) / TE, GM_GRID);
+  const size_t ldsBytes = sizeof(double) * (size_t)(J + 3) * TE;
+  k_gm_upd_dots<MULT><<<gb, 256, ldsBytes, h->stream>>>(n, h->dScal, h->dV, ld, J, h->dReduce, h->dW, Hcol, 1,
+                                                        h->dPartials);
+  k_gm_reduce_cols<<<J, 256, 0, h->stream>>>(h->dPartials, gb, h->dReduce, h->dScal);
+}
+
 // Arnoldi step j bookkeeping: H(j+1,j), Givens rotations, implicit residual, history
 __global__ void k_gm_scal_step(SolverScalars *sc, const double *red, double *H, double *cs, double *sn,
                                double *g, double *hist, int m, int j)
@@ -978,6 +1164,7 @@ int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int check
     h->hCap = m;
   }
   const int vb = vec_grid(n);
+  static const bool fusedIcgs = !(getenv("NG_GMRES_FUSED") && atoi(getenv("NG_GMRES_FUSED")) == 0);
   SolverScalars sc;
   int enq = 0;
   for (int cycle = 0;; ++cycle) {
@@ -1007,6 +1194,26 @@ int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int check
         NG_TRY((spmv_with_halo<false, true>(h, vj, h->dW, true, &sb)));
       }
       double *Hcol = h->dH + (size_t)j * (m + 1);
+      if (fusedIcgs && j + 1 <= GM_MAXV && n < (1LL << 29)) {
+        // ICGS with three sweeps over V instead of four: dots | update + dots | update + norm
+        const int J = j + 1;
+        if (J <= 8) {
+          k_gm_dots<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dV, ld, 0, J, h->dW, h->dPartials);
+          NG_TRY(reduce_partials(h, J, vb, 0));
+        } else {
+          const int gb = (int)std::min<long long>((n + GM_TILE - 1) / GM_TILE, GM_GRID);
+          k_gm_dots_all<<<gb, 256, 0, h->stream>>>(n, h->dScal, h->dV, ld, J, h->dW, h->dPartials);
+          k_gm_reduce_cols<<<J, 256, 0, h->stream>>>(h->dPartials, gb, h->dReduce, h->dScal);
+        }
+        NG_TRY(allreduce(h, J));
+        if (J <= 4) launch_upd_dots<8>(h, n, ld, J, Hcol);  // (J + 3) * 8 KiB of LDS
+        else if (J <= GM_MAXV / 4) launch_upd_dots<4>(h, n, ld, J, Hcol);
+        else if (J <= GM_MAXV / 2) launch_upd_dots<2>(h, n, ld, J, Hcol);
+        else launch_upd_dots<1>(h, n, ld, J, Hcol);
+        NG_TRY(allreduce(h, J));
+        k_gm_update<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dV, ld, J, h->dReduce, h->dW, Hcol, 0,
+                                               h->dPartials, 1);
+      } else
       for (int pass = 0; pass < 2; ++pass) {  // ICGS: two classical Gram-Schmidt passes
         for (int i0 = 0; i0 <= j; i0 += 8) {
           const int nv = std::min(8, j + 1 - i0);
