@@ -66,12 +66,12 @@ def build_rank(n, rank, nranks, device):
     return S, F, g, comm
 
 
-def cpu_baseline(n_cpu):
+def cpu_baseline(n_cpu, workload="continuity"):
     """The oracle ("port" of the reference algorithm: AoS gathers, per-edge sumInto with
-    sorted-row scan, CSR SpMV, Jacobi-CG) timed on the host cores for ONE step on an n_cpu^3
-    box -- a bounded sample of the same workload.  Multi-core flavour: the same source with
-    its OpenMP pragmas on, one owner-computes row block per core (the reference runs one MPI
-    rank per core); the 1-core figure is reported next to it."""
+    sorted-row scan, CSR SpMV, Jacobi-CG / GMRES) timed on the host cores for ONE step of the
+    benchmarked workload on an n_cpu^3 box -- a bounded sample of it.  Multi-core flavour:
+    the same source with its OpenMP pragmas on, one owner-computes row block per core (the
+    reference runs one MPI rank per core); the 1-core figure is reported next to it."""
     import nalu_amd
     from nalu_amd import synth
     from oracle import pyoracle as po
@@ -84,26 +84,40 @@ def cpu_baseline(n_cpu):
     dpdx = synth.quadratic_grad(xyz, 0)
     vel, rho = synth.velocity(xyz), synth.density(xyz)
     areaT = np.ascontiguousarray(area.T)
+    scalar = workload == "scalar"
+    if scalar:  # the same inputs and options as main() sets up on the GPU
+        q, dqdx = synth.quadratic(xyz, 1), synth.quadratic_grad(xyz, 1)
+        gamma = np.full(S.n_local, 0.2)
+        mdot = po.compute_mdot(S.edge_nodes, areaT, xyz, dpdx, vel, p, rho, 0.1, fast=True)
+        opts = po.scalar_opts(alpha_upw=1.0, upw_factor=1.0, limiter=True, hybrid_factor=1.0)
+        nodes = np.arange(S.n_owned, dtype=np.int32).reshape(-1, 1)
 
     def one_step(flavour):
         po.build(fast=flavour)
         ls = po.LinSys(1, S.n_owned, fast=flavour)
         ls.add_connections(S.edge_nodes)
+        if scalar:
+            ls.add_connections(nodes)
         ls.finalize()
         t0 = time.perf_counter()
         ls.zero()
-        ls.assemble_continuity(S.edge_nodes, areaT, xyz, dpdx, vel, p, rho, 0.1)
-        ls.reset_rows([0])
-        ls.sum_into([0], [0.0 - p[0]], [1.0])
+        if scalar:
+            ls.assemble_scalar(S.edge_nodes, areaT, mdot, xyz, dqdx, vel, q, rho, gamma, opts)
+            ls.assemble_scalar_mass_be(0.9 * q, q, rho, rho, vol, 0.1)
+        else:
+            ls.assemble_continuity(S.edge_nodes, areaT, xyz, dpdx, vel, p, rho, 0.1)
+            ls.reset_rows([0])
+            ls.sum_into([0], [0.0 - p[0]], [1.0])
         t1 = time.perf_counter()
-        out = ls.solve("cg", "jacobi", tolerance=1e-5, max_iterations=50)
+        out = ls.solve("gmres" if scalar else "cg", "jacobi", tolerance=1e-5, max_iterations=50, kspace=50)
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1, out["iters"]
 
     a1, s1, it1 = one_step(True)
     am, sm, itm = min(one_step("omp"), one_step("omp"), key=lambda r: r[0] + r[1])  # best of two
+    what = "GMRES(50)/Jacobi" if scalar else "Jacobi-CG"
     return dict(value=S.n_edges / (am + sm), unit="edges/s", cores=cores, kind="port",
-                sample=f"1 step (assemble + {itm} Jacobi-CG its) on a {n_cpu}^3-node box, "
+                sample=f"1 step ({workload} assembly + {itm} {what} its) on a {n_cpu}^3-node box, "
                        f"oracle/nalu_oracle.c -O3 -march=native -fopenmp, {cores} threads: "
                        f"assemble {S.n_edges / am:.3e} edges/s, solve {sm * 1e3 / max(itm, 1):.1f} ms/it; "
                        f"1 thread: {S.n_edges / (a1 + s1):.3e} edges/s/step, assemble "
@@ -243,7 +257,7 @@ def main():
                          "bound": "hbm",
                          "achieved": spmv_bytes / spmv_t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": spmv_bytes / spmv_t / 1e9 / HBM_PEAK_GBS,
-                         "traffic": pmc.get("k_spmv", {}).get("hbm_bytes"),
+                         "traffic": pmc.get("k_spmv", {}).get("hbm_bytes") if a.workload == "continuity" else None,
                          "algorithmic_bytes": spmv_bytes, "avg_ms": spmv_t * 1e3, "launches": spmv_cnt},
             "roofline_assembly": {"kernel": f"k_assemble_rows<{'ContOp' if a.workload == 'continuity' else 'ScalOp'}> ({a.mode})", "bound": "hbm",
                                   "achieved": asm_bytes / asm_t / 1e9, "peak": HBM_PEAK_GBS,
@@ -257,7 +271,7 @@ def main():
         if variants:
             out["scatter_variants"] = variants
         if world == 1 and a.cpu_n > 0:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_n)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.workload)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
