@@ -107,6 +107,7 @@ public:
     else throw std::runtime_error("solver method '" + method_ + "' not supported on the GPU (cg, gmres)");
     if (precond_ == "jacobi" || precond_ == "default") c.precond = NALU_GPU_PRECOND_JACOBI;
     else if (precond_ == "sgs") c.precond = NALU_GPU_PRECOND_SGS;
+    else if (precond_ == "mt_sgs") c.precond = NALU_GPU_PRECOND_MT_SGS;
     else if (precond_ == "chebyshev") c.precond = NALU_GPU_PRECOND_CHEBYSHEV;
     else if (precond_ == "none") c.precond = NALU_GPU_PRECOND_NONE;
     else throw std::runtime_error("preconditioner '" + precond_ + "' not supported on the GPU");

@@ -42,7 +42,8 @@ enum {
 
 enum { NALU_GPU_METHOD_CG = 0, NALU_GPU_METHOD_GMRES = 1 };
 enum { NALU_GPU_PRECOND_NONE = 0, NALU_GPU_PRECOND_JACOBI = 1, NALU_GPU_PRECOND_SGS = 2,
-       NALU_GPU_PRECOND_CHEBYSHEV = 3 };
+       NALU_GPU_PRECOND_CHEBYSHEV = 3,
+       NALU_GPU_PRECOND_MT_SGS = 4 /* "mt_sgs" (src/LinearSolverConfig.C:76-80): multicolour SGS */ };
 enum { NALU_GPU_PECLET_CLASSIC = 0, NALU_GPU_PECLET_TANH = 1 };
 
 const char *nalu_gpu_last_error(void);

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("NALU_GPU_LIB", os.path.join(_HERE, "libnalu_gpu.so"))
 
 SCATTER = {"rows": 0, "colored": 1, "atomic": 2}
 METHOD = {"cg": 0, "gmres": 1}
-PRECOND = {"none": 0, "jacobi": 1, "default": 1, "sgs": 2, "chebyshev": 3}
+PRECOND = {"none": 0, "jacobi": 1, "default": 1, "sgs": 2, "chebyshev": 3, "mt_sgs": 4}
 PECLET = {"classic": 0, "tanh": 1}
 TIMERS = {"zero": 0, "assemble_edges": 1, "spmv": 2, "solve": 3, "precond": 4, "bc": 5}
 

@@ -148,6 +148,11 @@ struct nalu_gpu_linsys {
   std::vector<int> sgsFwdOff, sgsBwdOff;
   int *dSgsFwdRows = nullptr, *dSgsBwdRows = nullptr;
 
+  // multicolour SGS (precond.hip): rows bucketed by greedy colour
+  bool mcReady = false;
+  std::vector<int> mcOff;
+  int *dMcRows = nullptr;
+
   // Chebyshev preconditioner (solve.hip)
   double *dChebV = nullptr;      // nOwned
   double *dChebStart = nullptr;  // nCols: power-method start vector (hash of the global ids)
@@ -245,5 +250,7 @@ int finish_reduction(nalu_gpu_linsys *h, int nslots, int nblocks, const double *
 int vec_grid(int64_t n);
 int ensure_sgs_levels(nalu_gpu_linsys *h);
 int apply_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone);
+int ensure_mc_colors(nalu_gpu_linsys *h);
+int apply_mc_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone);
 
 }  // namespace nalu_gpu

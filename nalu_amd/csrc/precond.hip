@@ -64,6 +64,38 @@ __global__ __launch_bounds__(256) void k_sgs_backward(SellView A, const int *__r
   z[i] = t[i] - s * dinv[i];
 }
 
+// Multicolour SGS ("mt_sgs"): rows of one colour are not coupled, so a sweep is one launch per
+// colour.  t and z start at zero: only colours already visited contribute, and no colour
+// comparison is needed.  Columns of regular rows are computed from the slice offsets.
+template <bool FWD>
+__global__ __launch_bounds__(256) void k_mc_sweep(SellView A, const int *__restrict__ rows, int n,
+                                                   const SolverScalars *__restrict__ sc,
+                                                   const double *__restrict__ dinv,
+                                                   const double *__restrict__ r, const double *__restrict__ t,
+                                                   double *out)
+{
+  if (sc && sc->done) return;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int i = rows[q];
+  const int slice = i / SELL_C, lane = i % SELL_C;
+  const long long off0 = A.sliceOff[slice];
+  const long long off = off0 + lane;
+  const int w = A.sliceWidth[slice];
+  const int *kOff = A.kOff + off0 / SELL_C;
+  const bool ex = (A.exMask[(size_t)slice * 4 + (lane >> 6)] >> (lane & 63)) & 1ULL;
+  double s = FWD ? r[i] : 0.0;
+  for (int k = 0; k < w; ++k) {
+    const long long pos = off + (long long)k * SELL_C;
+    const int c = ex ? A.cols[pos] : i + kOff[k];
+    if (c != i && c < A.nRows) {
+      if (FWD) s -= A.vals[pos] * out[c];
+      else s += A.vals[pos] * out[c];
+    }
+  }
+  out[i] = FWD ? s * dinv[i] : t[i] - s * dinv[i];
+}
+
 // rows sorted by level (ascending row inside a level) + level offsets
 void bucket_by_level(const std::vector<int> &level, int nLevels, std::vector<int> &rows,
                      std::vector<int> &off)
@@ -131,6 +163,60 @@ int nalu_gpu::apply_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool use
     const int o = h->sgsBwdOff[l], cnt = h->sgsBwdOff[l + 1] - o;
     k_sgs_backward<<<(cnt + 255) / 256, 256, 0, h->stream>>>(A, h->dSgsBwdRows + o, cnt, sc, h->dDinv,
                                                              h->dT, z);
+  }
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+// greedy colouring in row order (the oracle's orc_greedy_colors): colour of row i = smallest
+// colour none of its lower-numbered owned neighbours has
+int nalu_gpu::ensure_mc_colors(nalu_gpu_linsys *h)
+{
+  if (h->mcReady) return NALU_GPU_OK;
+  const int n = h->nOwned;
+  std::vector<int> color((size_t)n, 0);
+  int nc = 0;
+  for (int i = 0; i < n; ++i) {
+    unsigned long long used = 0;
+    for (int64_t k = h->rowPtr[i]; k < h->rowPtr[i + 1]; ++k) {
+      const int c = h->colIdx[k];
+      if (c < i) used |= 1ull << color[c];
+    }
+    int col = 0;
+    while (col < 63 && ((used >> col) & 1ull)) ++col;
+    NG_REQUIRE(col < 63, NALU_GPU_EUNSUPPORTED, "mt_sgs: the graph needs more than 63 colours");
+    color[i] = col;
+    nc = std::max(nc, col + 1);
+  }
+  std::vector<int> rows;
+  bucket_by_level(color, nc, rows, h->mcOff);
+  NG_HIP(hipMalloc(&h->dMcRows, sizeof(int) * (size_t)std::max(n, 1)));
+  NG_HIP(hipMemcpy(h->dMcRows, rows.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  h->mcReady = true;
+  return NALU_GPU_OK;
+}
+
+// z = multicolour SGS(r) on the owned rows; uses h->dT as the intermediate vector.
+int nalu_gpu::apply_mc_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone)
+{
+  NG_TRY(ensure_mc_colors(h));
+  const SellView A = sell_view(h);
+  const SolverScalars *sc = useDone ? h->dScal : nullptr;
+  const int nc = (int)h->mcOff.size() - 1;
+  const size_t bytes = sizeof(double) * (size_t)h->nOwned;
+  NG_HIP(hipMemsetAsync(h->dT, 0, bytes, h->stream));
+  NG_HIP(hipMemsetAsync(z, 0, bytes, h->stream));
+  for (int c = 0; c < nc; ++c) {
+    const int o = h->mcOff[c], cnt = h->mcOff[c + 1] - o;
+    if (cnt)
+      k_mc_sweep<true><<<(cnt + 255) / 256, 256, 0, h->stream>>>(A, h->dMcRows + o, cnt, sc, h->dDinv, r,
+                                                                 nullptr, h->dT);
+  }
+  for (int c = nc - 1; c >= 0; --c) {
+    const int o = h->mcOff[c], cnt = h->mcOff[c + 1] - o;
+    if (cnt)
+      k_mc_sweep<false><<<(cnt + 255) / 256, 256, 0, h->stream>>>(A, h->dMcRows + o, cnt, sc, h->dDinv,
+                                                                  nullptr, h->dT, z);
   }
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;

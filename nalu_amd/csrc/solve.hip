@@ -490,7 +490,9 @@ int apply_cheb(nalu_gpu_linsys *h, const double *r, double *x, bool useDone)
 // z = M^-1 r for the preconditioners that are not a diagonal scaling
 int apply_general(nalu_gpu_linsys *h, int precond, const double *r, double *z, bool useDone)
 {
-  return precond == NALU_GPU_PRECOND_CHEBYSHEV ? apply_cheb(h, r, z, useDone) : apply_sgs(h, r, z, useDone);
+  if (precond == NALU_GPU_PRECOND_CHEBYSHEV) return apply_cheb(h, r, z, useDone);
+  if (precond == NALU_GPU_PRECOND_MT_SGS) return apply_mc_sgs(h, r, z, useDone);
+  return apply_sgs(h, r, z, useDone);
 }
 
 // ------------------------------------------------------------------------- CG
@@ -1141,7 +1143,8 @@ __global__ __launch_bounds__(256) void k_gm_combine(long long n, const SolverSca
 
 int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEvery)
 {
-  const bool sgs = cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV;
+  const bool sgs = cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV ||
+                   cfg->precond == NALU_GPU_PRECOND_MT_SGS;
   const long long n = h->nOwned, ld = h->nCols;
   const int m = cfg->kspace;
   NG_REQUIRE(m >= 1 && m + 1 <= REDUCE_CAP, NALU_GPU_EINVAL, "kspace must be in [1,%d]", REDUCE_CAP - 1);
@@ -1307,9 +1310,10 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
   NG_REQUIRE(cfg->method == NALU_GPU_METHOD_CG || cfg->method == NALU_GPU_METHOD_GMRES,
              NALU_GPU_EUNSUPPORTED, "solver method %d (supported: cg, gmres)", cfg->method);
   NG_REQUIRE(cfg->precond == NALU_GPU_PRECOND_NONE || cfg->precond == NALU_GPU_PRECOND_JACOBI ||
-                 cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV,
+                 cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV ||
+                 cfg->precond == NALU_GPU_PRECOND_MT_SGS,
              NALU_GPU_EUNSUPPORTED,
-             "preconditioner %d (supported: none, jacobi, sgs, chebyshev; the reference throws on unknown "
+             "preconditioner %d (supported: none, jacobi, sgs, mt_sgs, chebyshev; the reference throws on unknown "
              "names, src/LinearSolverConfig.C:97-99)", cfg->precond);
   NG_REQUIRE(cfg->max_iterations >= 0 && cfg->tolerance >= 0.0, NALU_GPU_EINVAL, "bad solver limits");
   NG_TRY(materialize_zero(h));
@@ -1324,6 +1328,7 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
                                                                    cfg->precond != NALU_GPU_PRECOND_NONE,
                                                                    h->dDinv);
   if (cfg->precond == NALU_GPU_PRECOND_SGS) NG_TRY(ensure_sgs_levels(h));
+  if (cfg->precond == NALU_GPU_PRECOND_MT_SGS) NG_TRY(ensure_mc_colors(h));
   NG_HIP(hipGetLastError());
   NG_TRY(halo_exchange(h, h->dDinv));
   if (cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV) NG_TRY(cheb_compute(h));
@@ -1333,7 +1338,8 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
 
   timer_begin(h, NALU_GPU_T_SOLVE);
   if (cfg->method == NALU_GPU_METHOD_CG &&
-      (cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV))
+      (cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV ||
+       cfg->precond == NALU_GPU_PRECOND_MT_SGS))
     NG_TRY(solve_cg_general(h, cfg, checkEvery));
   else if (cfg->method == NALU_GPU_METHOD_CG) NG_TRY(solve_cg(h, cfg, checkEvery));
   else NG_TRY(solve_gmres(h, cfg, checkEvery));

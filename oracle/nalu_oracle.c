@@ -1060,6 +1060,82 @@ static void cheb_apply(const orc_linsys *ls, const double *dinv, const double *r
   free(w); free(v);
 }
 
+/* Multicolour symmetric Gauss-Seidel ("mt_sgs", src/LinearSolverConfig.C:76-80: Ifpack2's
+ * "MT Symmetric Gauss-Seidel", the KokkosKernels coloured sweep; Trilinos code, not in the
+ * tree: PARITY UNPINNED, and KokkosKernels' colouring is its own).  Here: greedy colouring in
+ * row order (colour of row i = smallest colour none of its lower-numbered owned neighbours
+ * has), then one SGS sweep, zero starting solution, in (colour, row) order:
+ *   forward, colours ascending:   t_i = (r_i - sum_{c != i} a_ic t_c) / d_i
+ *   backward, colours descending: z_i = t_i - (sum_{c != i} a_ic z_c) / d_i
+ * with t and z starting at zero, so that only already-visited colours contribute (rows of
+ * one colour are not coupled).  Off-rank columns are ignored as in the processor-local SGS. */
+static int *g_mc_color = NULL, *g_mc_rows = NULL, *g_mc_off = NULL;
+static int g_mc_ncolors = 0;
+static int64_t g_mc_n = -1;
+
+int orc_greedy_colors(const orc_linsys *ls, int *color)
+{
+  const orc_graph *g = ls->ownedGraph;
+  const int64_t n = g->nrows;
+  int ncolors = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    uint64_t used = 0; /* up to 64 colours */
+    for (size_t k = g->rowPointers[i]; k < g->rowPointers[i + 1]; ++k) {
+      const int c = g->colIndices[k];
+      if (c < i) used |= 1ull << color[c];
+    }
+    int col = 0;
+    while (col < 63 && ((used >> col) & 1ull)) ++col;
+    color[i] = col;
+    if (col + 1 > ncolors) ncolors = col + 1;
+  }
+  return ncolors;
+}
+
+static void mc_sgs_setup(const orc_linsys *ls)
+{
+  const int64_t n = ls->ownedGraph->nrows;
+  free(g_mc_color); free(g_mc_rows); free(g_mc_off);
+  g_mc_color = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
+  g_mc_rows = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
+  g_mc_ncolors = orc_greedy_colors(ls, g_mc_color);
+  g_mc_off = (int *)calloc((size_t)g_mc_ncolors + 2, sizeof(int));
+  for (int64_t i = 0; i < n; ++i) ++g_mc_off[g_mc_color[i] + 1];
+  for (int c = 0; c < g_mc_ncolors; ++c) g_mc_off[c + 1] += g_mc_off[c];
+  int *cur = (int *)malloc(sizeof(int) * (size_t)(g_mc_ncolors + 1));
+  memcpy(cur, g_mc_off, sizeof(int) * (size_t)(g_mc_ncolors + 1));
+  for (int64_t i = 0; i < n; ++i) g_mc_rows[cur[g_mc_color[i]]++] = (int)i;
+  free(cur);
+  g_mc_n = n;
+}
+
+static void mc_sgs_apply(const orc_linsys *ls, const double *dinv, const double *r, double *z, double *t)
+{
+  const orc_graph *g = ls->ownedGraph;
+  const int64_t n = g->nrows;
+  for (int64_t i = 0; i < n; ++i) { t[i] = 0.0; z[i] = 0.0; }
+  for (int col = 0; col < g_mc_ncolors; ++col)
+    for (int q = g_mc_off[col]; q < g_mc_off[col + 1]; ++q) {
+      const int i = g_mc_rows[q];
+      double s = r[i];
+      for (size_t k = g->rowPointers[i]; k < g->rowPointers[i + 1]; ++k) {
+        const int c = g->colIndices[k];
+        if (c != i && c < n) s -= ls->ownedVals[k] * t[c];
+      }
+      t[i] = s * dinv[i];
+    }
+  for (int col = g_mc_ncolors - 1; col >= 0; --col)
+    for (int q = g_mc_off[col]; q < g_mc_off[col + 1]; ++q) {
+      const int i = g_mc_rows[q];
+      double s = 0.0;
+      for (size_t k = g->rowPointers[i]; k < g->rowPointers[i + 1]; ++k) {
+        const int c = g->colIndices[k];
+        if (c != i && c < n) s += ls->ownedVals[k] * z[c];
+      }
+      z[i] = t[i] - s * dinv[i];
+    }
+}
+
 static void apply_precond(const orc_linsys *ls, int precond, const double *dinv,
                           const double *r, double *z, double *tmp)
 {
@@ -1067,6 +1143,8 @@ static void apply_precond(const orc_linsys *ls, int precond, const double *dinv,
   const int64_t n = g->nrows;
   if (precond == 3) {
     cheb_apply(ls, dinv, r, z);
+  } else if (precond == 4) {
+    mc_sgs_apply(ls, dinv, r, z, tmp);
   } else if (precond == 0) {
     memcpy(z, r, sizeof(double) * (size_t)n);
   } else if (precond == 1) {
@@ -1114,6 +1192,7 @@ int orc_solve(orc_linsys *ls, const orc_solver_config *cfg, double *finalResidNr
   }
   double *tmp = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
   if (cfg->precond == 3) g_cheb_lambda_max = cheb_power_method(ls, dinv); /* compute() */
+  if (cfg->precond == 4) mc_sgs_setup(ls);                               /* compute() */
   for (int64_t i = 0; i < n; ++i) x[i] = 0.0; /* zeroSystem: x0 = 0 */
 
   const double r0 = orc_norm2(b, n);

@@ -176,7 +176,8 @@ void orc_spmv(const orc_linsys *ls, const double *x, double *y);
 typedef struct {
   int method;  /* 0 = cg, 1 = gmres */
   int precond; /* 0 = none, 1 = jacobi (src/LinearSolverConfig.C:81-85), 2 = sgs (:71-75),
-                  3 = chebyshev (not a reference option: see cheb_apply in nalu_oracle.c) */
+                  3 = chebyshev (not a reference option: see cheb_apply in nalu_oracle.c),
+                  4 = mt_sgs (:76-80), multicolour SGS: see mc_sgs_apply in nalu_oracle.c */
   double tolerance;
   int max_iterations;
   int kspace;
@@ -189,6 +190,8 @@ typedef struct {
 int orc_solve(orc_linsys *ls, const orc_solver_config *cfg, double *finalResidNrm,
               double *history, int history_cap, int *history_len);
 double orc_norm2(const double *v, int64_t n);
+/* greedy colouring in row order used by precond 4; color has nrows entries; returns #colours */
+int orc_greedy_colors(const orc_linsys *ls, int *color);
 
 #ifdef __cplusplus
 }

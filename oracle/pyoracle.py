@@ -64,7 +64,7 @@ class SolverConfig(C.Structure):
 
 
 METHODS = {"cg": 0, "gmres": 1}
-PRECONDS = {"none": 0, "jacobi": 1, "default": 1, "sgs": 2, "chebyshev": 3}
+PRECONDS = {"none": 0, "jacobi": 1, "default": 1, "sgs": 2, "chebyshev": 3, "mt_sgs": 4}
 
 
 def _bind(lib):
@@ -120,6 +120,8 @@ def _bind(lib):
                               _dp, C.c_int, C.POINTER(C.c_int)]
     lib.orc_solve.restype = C.c_int
     lib.orc_norm2.argtypes = [_dp, C.c_int64]
+    lib.orc_greedy_colors.argtypes = [C.POINTER(_LinSys), _ip]
+    lib.orc_greedy_colors.restype = C.c_int
     lib.orc_norm2.restype = C.c_double
     return lib
 
@@ -267,6 +269,12 @@ class LinSys:
     def assemble_scalar_mass_be(self, qN, qNp1, rhoN, rhoNp1, vol, dt):
         self.L.orc_assemble_scalar_mass_be(self.p, len(qN), f64(qN), f64(qNp1), f64(rhoN),
                                            f64(rhoNp1), f64(vol), dt)
+
+    def greedy_colors(self):
+        """the row-order greedy colouring of the mt_sgs preconditioner: (colours, count)"""
+        col = np.zeros(max(self.n_owned * self.num_dof, 1), np.int32)
+        nc = self.L.orc_greedy_colors(self.p, col)
+        return col[:self.n_owned * self.num_dof], nc
 
     def spmv(self, x):
         y = np.zeros(self.n_owned * self.num_dof)

@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 S, F, g, _ = build_rank(n, 0, 1, "cuda:0")
 p0 = float(F["p"][0].item())
 res = {"n": n}
-for method, pc, its in (("cg", "jacobi", 50), ("cg", "chebyshev", 50), ("cg", "sgs", 10), ("gmres", "jacobi", 20), ("gmres", "chebyshev", 20), ("gmres", "sgs", 10)):
+for method, pc, its in (("cg", "jacobi", 50), ("cg", "chebyshev", 50), ("cg", "mt_sgs", 50), ("gmres", "mt_sgs", 20), ("cg", "sgs", 10), ("gmres", "jacobi", 20), ("gmres", "chebyshev", 20), ("gmres", "sgs", 10)):
     cfg = nalu_amd.LinearSolverConfig(method=method, preconditioner=pc, tolerance=1e-12, max_iterations=its, kspace=50)
     for rep in range(2):
         g.zeroSystem()

@@ -207,6 +207,10 @@ def _pin(ls, g, c, node=0):
     ("gmres", "sgs", dict(tolerance=1e-10, max_iterations=200, kspace=50)),
     ("gmres", "sgs", dict(tolerance=1e-6, max_iterations=40, kspace=5)),
     ("cg", "sgs", dict(tolerance=1e-10, max_iterations=300)),
+    # mt_sgs (src/LinearSolverConfig.C:76-80): multicolour SGS on the greedy row-order colouring
+    # (two colours on the lattice), one launch per colour; same sweeps as the oracle's
+    ("gmres", "mt_sgs", dict(tolerance=1e-10, max_iterations=200, kspace=50)),
+    ("cg", "mt_sgs", dict(tolerance=1e-10, max_iterations=300)),
     # Chebyshev(2, ratio 20, 15 power iterations): Ifpack2's algorithm restated (parity unpinned)
     ("cg", "chebyshev", dict(tolerance=1e-10, max_iterations=300)),
     ("gmres", "chebyshev", dict(tolerance=1e-10, max_iterations=200, kspace=50)),
@@ -531,7 +535,8 @@ def test_element_graph_27_point_rows(G, torch, oracle):
     g.spmv(torch.as_tensor(x, device="cuda:0"), y)
     g.synchronize()
     assert np.array_equal(y.cpu().numpy(), ls.spmv(x))
-    for method, pc in (("gmres", "jacobi"), ("gmres", "sgs"), ("gmres", "chebyshev"), ("cg", "sgs")):
+    for method, pc in (("gmres", "jacobi"), ("gmres", "sgs"), ("gmres", "chebyshev"), ("cg", "sgs"),
+                       ("gmres", "mt_sgs")):  # mt_sgs: eight colours on the 27-point graph
         kw = dict(tolerance=1e-11, max_iterations=120, kspace=40)
         ref = ls.solve(method, pc, **kw)
         g.solve(G.LinearSolverConfig(method=method, preconditioner=pc, **kw))

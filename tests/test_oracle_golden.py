@@ -321,3 +321,35 @@ def test_cg_spd(oracle):
     out = ls.solve("cg", "jacobi", tolerance=1e-12, max_iterations=300)
     np.testing.assert_allclose(out["x"], spl.spsolve(A.tocsc(), b), rtol=1e-9, atol=1e-12)
     assert np.all(np.diff(out["history"]) < 0.5)  # no blow-up
+
+
+def test_multicolour_sgs(oracle):
+    """mt_sgs: the greedy row-order colouring is proper, red-black on the lattice and eight
+    colours on the 27-point element graph; one application equals the dense
+    (D+U')^-1 D (D+L')^-1 r in (colour, row) order."""
+    m = oracle.BoxMesh(5, 4, 3, perturb=0.1)
+    for ents, want in ((m.edge_nodes, 2), (m.hex_nodes, 8)):
+        ls = oracle.LinSys(1, m.nnodes)
+        ls.add_connections(ents)
+        ls.finalize()
+        col, nc = ls.greedy_colors()
+        rp, ci, _ = ls.owned_csr()
+        rows = np.repeat(np.arange(m.nnodes), np.diff(rp))
+        off = rows != ci
+        assert nc == want and not (col[rows[off]] == col[ci[off]]).any()
+        rs = np.random.RandomState(5)
+        v = rs.uniform(-1, 1, len(ci))
+        v[~off] = np.bincount(rows, np.abs(v), m.nnodes) + 1.0
+        oracle.set_values(ls, v)
+        A = dense(rp, ci, v, m.nnodes)
+        key = col.astype(np.int64) * m.nnodes + np.arange(m.nnodes)
+        before = key[None, :] < key[:, None]  # column visited before the row
+        D = np.diag(np.diag(A))
+        Lp, Up = A * before, A * (~before) - D
+        b = rs.uniform(-1, 1, m.nnodes)
+        oracle.set_rhs(ls, b)
+        # one iteration of preconditioned CG from x0 = 0 moves along z = M^-1 b
+        out = ls.solve("cg", "mt_sgs", tolerance=1e-30, max_iterations=1)
+        z = np.linalg.solve(D + Up, D @ np.linalg.solve(D + Lp, b))
+        alpha = (b @ z) / (z @ (A @ z))
+        np.testing.assert_allclose(out["x"], alpha * z, rtol=1e-12, atol=1e-14)
