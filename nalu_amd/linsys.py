@@ -193,6 +193,31 @@ class GpuLinearSystem:
         mmio.write_dense(names["sln"], self.solution())
         return names
 
+    def readFromFile(self, base_filename, n_ranks=1, read_rhs=True):
+        """Load the matrix values (and rhs) of a `writeToFile` dump -- this library's or a
+        Trilinos run's -- into the assembled system.  The entries are matched to the graph by
+        global (row, column) id, so their order in the file is free; an entry outside the
+        graph, or a graph entry the file lacks, is an error."""
+        from . import mmio
+        names = mmio.file_names(base_filename, self.writeCounter, n_ranks, self.my_rank)
+        _, _, r, c, v = mmio.read_sparse(names["mm"])
+        rp, ci = self.graph()
+        rows = np.repeat(np.arange(self.n_rows), np.diff(rp))
+        span = int(self.gids.max()) + 1
+        have = self.gids[rows].astype(np.int64) * span + self.gids[ci]
+        order = np.argsort(have, kind="stable")
+        want = r * span + c
+        pos = np.searchsorted(have[order], want)
+        ok = (pos < len(have)) & (have[order][np.minimum(pos, len(have) - 1)] == want)
+        if not ok.all() or len(np.unique(want)) != len(have):
+            raise RuntimeError(f"{names['mm']} does not match the graph of this linear system")
+        vals = np.empty(self.nnz)
+        vals[order[pos]] = v
+        self.set_matrix_values(vals)
+        if read_rhs:
+            self.set_rhs(mmio.read_dense(names["rhs"]))
+        return names
+
     # ---- assembly -------------------------------------------------------------
     def zeroSystem(self):
         L.check(self.lib.nalu_gpu_zero_system(self.h))

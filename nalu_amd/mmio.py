@@ -45,3 +45,36 @@ def write_dense(path, vec):
         f.write("%%MatrixMarket matrix array real general\n")
         f.write(f"{len(v)} 1\n")
         np.savetxt(f, v, fmt="%.17e")
+
+
+def read_sparse(path):
+    """-> (n_rows, n_cols, rows, cols, vals) of a `coordinate real general` file, 1-based ids
+    as stored (the order of the entries in the file is kept)."""
+    with open(path) as f:
+        head = f.readline().split()
+        if [w.lower() for w in head[:5]] != ["%%matrixmarket", "matrix", "coordinate", "real", "general"]:
+            raise ValueError(f"{path}: not a 'matrix coordinate real general' MatrixMarket file")
+        line = f.readline()
+        while line.startswith("%"):
+            line = f.readline()
+        nr, nc, nnz = (int(t) for t in line.split())
+        data = np.loadtxt(f, dtype=np.float64, ndmin=2) if nnz else np.zeros((0, 3))
+    if data.shape != (nnz, 3):
+        raise ValueError(f"{path}: expected {nnz} entries, found {data.shape[0]}")
+    return nr, nc, data[:, 0].astype(np.int64), data[:, 1].astype(np.int64), data[:, 2].copy()
+
+
+def read_dense(path):
+    """-> the n x 1 vector of an `array real general` file"""
+    with open(path) as f:
+        head = f.readline().split()
+        if [w.lower() for w in head[:5]] != ["%%matrixmarket", "matrix", "array", "real", "general"]:
+            raise ValueError(f"{path}: not a 'matrix array real general' MatrixMarket file")
+        line = f.readline()
+        while line.startswith("%"):
+            line = f.readline()
+        n, m = (int(t) for t in line.split())
+        v = np.loadtxt(f, dtype=np.float64, ndmin=1) if n * m else np.zeros(0)
+    if v.size != n * m:
+        raise ValueError(f"{path}: expected {n * m} values, found {v.size}")
+    return v

@@ -362,6 +362,25 @@ def test_matrix_market_dump(G, torch, oracle, tmp_path):
     assert np.array_equal(scipy.io.mmread(names["sln"]).ravel(), g.solution())
     with pytest.raises(RuntimeError):
         g.writeToFile(str(tmp_path / "x"), useOwned=False)
+    # ... and read back into a fresh system (the route by which a dump of a real Trilinos run
+    # is solved here): same graph, entries shuffled in the file, identical solve
+    hist, x = g.history.copy(), g.solution().copy()
+    lines = open(names["mm"]).read().splitlines()
+    k = next(i for i, l in enumerate(lines) if not l.startswith("%")) + 1
+    body = lines[k:]
+    np.random.RandomState(4).shuffle(body)
+    open(names["mm"], "w").write("\n".join(lines[:k] + body) + "\n")
+    g2 = c.gpu_system(G.GpuLinearSystem)
+    g2.writeCounter = 3
+    g2.zeroSystem()
+    g2.readFromFile(str(tmp_path / "ContinuityEQS"))
+    assert np.array_equal(g2.matrix_values(), v) and np.array_equal(g2.rhs(), ls.owned_rhs())
+    g2.solve(G.LinearSolverConfig(method="cg", preconditioner="jacobi", tolerance=1e-8,
+                                  max_iterations=200))
+    assert np.array_equal(g2.history, hist) and np.array_equal(g2.solution(), x)
+    open(names["mm"], "w").write("\n".join(lines[:k] + body[:-1]) + "\n")
+    with pytest.raises((RuntimeError, ValueError)):
+        g2.readFromFile(str(tmp_path / "ContinuityEQS"))
 
 
 def test_nodal_updates_of_the_projection_loop(G, torch, oracle):

@@ -1,4 +1,4 @@
-"""MatrixMarket writer (host logic, CPU): round trip through scipy.io.mmread."""
+"""MatrixMarket writer / reader (host logic, CPU): round trips through scipy.io.mmread and back."""
 import numpy as np
 import scipy.io
 import scipy.sparse as sp
@@ -24,3 +24,14 @@ def test_sparse_and_dense_round_trip(tmp_path):
     assert np.array_equal(scipy.io.mmread(names["rhs"]).ravel(), b)
     # multi-rank names carry the rank
     assert mmio.file_names("x", 0, 2, 1)["mm"] == "x-O-0.mm.2.1"
+    # the reader gives back exactly what was written (entry order kept)
+    nr, nc, r, c, v = mmio.read_sparse(names["mm"])
+    rows = np.repeat(np.arange(7), np.diff(A.indptr))
+    assert (nr, nc) == (7, 7) and np.array_equal(r, gids[rows]) and np.array_equal(c, gids[A.indices])
+    assert np.array_equal(v, A.data)
+    assert np.array_equal(mmio.read_dense(names["rhs"]), b)
+    import pytest
+    with pytest.raises(ValueError):
+        mmio.read_sparse(names["rhs"])
+    with pytest.raises(ValueError):
+        mmio.read_dense(names["mm"])
