@@ -279,6 +279,57 @@ public:
                "ScalarMassBackwardEulerNodeSuppAlg");
   }
 
+  // ---- the adjacent algorithms of the pressure-projection loop; each is one call
+  // ComputeMdotEdgeAlgorithm::execute (src/ComputeMdotEdgeAlgorithm.C:67-174)
+  void computeMdotEdges(const nalu_gpu_continuity_fields &f, double dt, double gamma1, double nocFac,
+                        double interpTogether, double *massFlowRate)
+  {
+    checkError(nalu_gpu_compute_mdot_edges(h_, &f, dt, gamma1, nocFac, interpTogether, massFlowRate),
+               "ComputeMdotEdgeAlgorithm");
+  }
+  // AssembleNodalGradEdgeAlgorithm::execute + driver zeroing (src/AssembleNodalGradEdgeAlgorithm.C:54-118)
+  void assembleNodalGradEdges(nalu_gpu_vec3 edgeAreaVec, const double *dualNodalVolume, const double *q,
+                              double *gx, double *gy, double *gz)
+  {
+    checkError(nalu_gpu_nodal_grad_edges(h_, edgeAreaVec, dualNodalVolume, q, gx, gy, gz),
+               "AssembleNodalGradEdgeAlgorithm");
+  }
+  // ComputeGeometryInteriorAlgorithm::execute for Hex8 (src/ComputeGeometryInteriorAlgorithm.C:78-216)
+  void computeGeometryHex8(int64_t nElem, const int *hexNodesDev, nalu_gpu_vec3 coordinates,
+                           double *dualNodalVolume, double *areaX, double *areaY, double *areaZ)
+  {
+    checkError(nalu_gpu_compute_geometry_hex8(h_, nElem, hexNodesDev, coordinates, dualNodalVolume, areaX,
+                                              areaY, areaZ),
+               "ComputeGeometryInteriorAlgorithm");
+  }
+  // field_axpby (src/FieldFunctions.C:24-58): y = alpha x + beta y
+  void fieldAxpby(int64_t n, double alpha, const double *x, double beta, double *y)
+  {
+    checkError(nalu_gpu_field_axpby(h_, n, alpha, x, beta, y), "field_axpby");
+  }
+  // LowMachEquationSystem::project_nodal_velocity (src/LowMachEquationSystem.C:772-855)
+  void projectNodalVelocity(int64_t n, double dt, double gamma1, nalu_gpu_vec3 dpdxNew, nalu_gpu_vec3 dpdxOld,
+                            const double *density, const unsigned char *projected, nalu_gpu_vec3 velocity)
+  {
+    checkError(nalu_gpu_project_nodal_velocity(h_, n, dt, gamma1, dpdxNew, dpdxOld, density, projected, velocity),
+               "project_nodal_velocity");
+  }
+
+  // ---- multi-GPU plumbing: the Tpetra Import / all-reduce equivalents are registered once
+  // after finalizeLinearSystem (see nalu_gpu.h; RcclComm.h gives the callbacks for RCCL)
+  void setHaloPlan(const std::vector<int> &neighborRanks, const std::vector<int> &sendOffsets,
+                   const std::vector<int> &sendLids, const std::vector<int> &recvOffsets)
+  {
+    if (sendOffsets.size() != neighborRanks.size() + 1 || recvOffsets.size() != neighborRanks.size() + 1)
+      throw std::runtime_error("setHaloPlan: offsets need one entry per neighbour plus one");
+    checkError(nalu_gpu_set_halo_plan(h_, (int)neighborRanks.size(), neighborRanks.data(), sendOffsets.data(),
+                                      sendLids.data(), recvOffsets.data()),
+               "setHaloPlan");
+  }
+  void setComm(const nalu_gpu_comm *comm) { checkError(nalu_gpu_set_comm(h_, comm), "setComm"); }
+  // stk::mesh::copy_owned_to_shared of one column-space field (src/LinearSystem.C:111-116)
+  void syncField(double *field) { checkError(nalu_gpu_halo_exchange(h_, field), "sync_field"); }
+
   // ---- Solve (src/TpetraLinearSystem.C:1709-1780)
   int solve(double *linearSolutionField)
   {

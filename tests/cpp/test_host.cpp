@@ -5,6 +5,7 @@
 //   test_host.bin             all tests (needs a GPU)
 //   test_host.bin --host-only the tests that touch no device
 #include "GpuLinearSystem.h"
+#include "RcclComm.h"
 #include "nalu_oracle.h"
 
 #include <hip/hip_runtime_api.h>
@@ -389,6 +390,93 @@ static void test_scalar_edge_assemble_and_solve(int n)
   orc_linsys_destroy(o);
 }
 
+// the adjacent algorithms of the projection loop through the host layer: bit-exact
+static void test_adjacent_algorithms()
+{
+  Box box(9);
+  Realm realm = box.realm();
+  LinearSolverConfig cfg;
+  GpuLinearSystem ls(realm, 1, "ContinuityEQS", &cfg);
+  ls.buildEdgeToNodeGraph(box.edges);
+  ls.finalizeLinearSystem();
+  DevVec3 xyz(box.xyz), dpdx(box.dpdx), vel(box.vel), area(box.area);
+  DevBuf p(box.p), rho(box.rho), vol(box.dualVol), mdot((size_t)box.E), g((size_t)3 * box.N);
+  nalu_gpu_continuity_fields f = {xyz.v(), dpdx.v(), vel.v(), p.p, rho.p, area.v()};
+  ls.computeMdotEdges(f, 0.1, 1.0, 1.0, 1.0, mdot.p);
+  ls.assembleNodalGradEdges(area.v(), vol.p, p.p, g.p, g.p + box.N, g.p + 2 * box.N);
+  ls.synchronize();
+  const std::vector<double> m = mdot.host(), gh = g.host();
+  EXPECT_TRUE(std::memcmp(m.data(), box.mdot.data(), m.size() * 8) == 0);
+  bool same = true;
+  for (int64_t i = 0; i < box.N && same; ++i)
+    for (int j = 0; j < 3; ++j) same = same && gh[(size_t)(j * box.N + i)] == box.dpdx[(size_t)(3 * i + j)];
+  EXPECT_TRUE(same);
+
+  // p += dp, then u -= (dt/gamma1)/rho (G_new - G_old)
+  std::vector<double> dp((size_t)box.N), gOld(box.dpdx), u(box.vel);
+  for (int64_t i = 0; i < box.N; ++i) dp[(size_t)i] = 0.01 * std::cos(3.0 * box.xyz[3 * i + 1]);
+  for (size_t i = 0; i < gOld.size(); ++i) gOld[i] *= 0.9;
+  std::vector<unsigned char> mask((size_t)box.N, 1);
+  for (int64_t i = 0; i < box.N; i += 7) mask[(size_t)i] = 0;
+  DevBuf dDp(dp), dP2(box.p);
+  ls.fieldAxpby(box.N, 1.0, dDp.p, 1.0, dP2.p);
+  std::vector<double> pRef(box.p);
+  orc_field_axpby(box.N, 1.0, dp.data(), 1.0, pRef.data());
+  unsigned char *dMask = nullptr;
+  HIP(hipMalloc((void **)&dMask, (size_t)box.N));
+  HIP(hipMemcpy(dMask, mask.data(), (size_t)box.N, hipMemcpyHostToDevice));
+  DevVec3 dOld(gOld), dU(box.vel);
+  ls.projectNodalVelocity(box.N, 0.1, 1.0, dpdx.v(), dOld.v(), rho.p, dMask, dU.v());
+  ls.synchronize();
+  orc_project_nodal_velocity(box.N, 0.1, 1.0, box.dpdx.data(), gOld.data(), box.rho.data(), mask.data(), u.data());
+  const std::vector<double> p2 = dP2.host(), uh = dU.buf.host();
+  EXPECT_TRUE(std::memcmp(p2.data(), pRef.data(), p2.size() * 8) == 0);
+  same = true;
+  for (int64_t i = 0; i < box.N && same; ++i)
+    for (int j = 0; j < 3; ++j) same = same && uh[(size_t)(j * box.N + i)] == u[(size_t)(3 * i + j)];
+  EXPECT_TRUE(same);
+  (void)hipFree(dMask);
+}
+
+// RcclComm on a one-rank communicator: every dot product of the solve goes through
+// ncclAllReduce on the library's reduce buffer; results equal the solve without a communicator
+static void test_rccl_comm_world_1(const char *method)
+{
+  Box box(10);
+  Realm realm = box.realm();
+  LinearSolverConfig cfg;
+  cfg.set(method, "jacobi", 1e-10, 150, 25);
+  DevVec3 xyz(box.xyz), dpdx(box.dpdx), vel(box.vel), area(box.area);
+  DevBuf p(box.p), rho(box.rho), x0((size_t)box.N), x1((size_t)box.N);
+  nalu_gpu_continuity_fields f = {xyz.v(), dpdx.v(), vel.v(), p.p, rho.p, area.v()};
+  std::vector<double> hist[2];
+  int iters[2] = {0, 0};
+  ncclComm_t comm;
+  int dev = 0;
+  EXPECT_TRUE(ncclCommInitAll(&comm, 1, &dev) == ncclSuccess);
+  for (int withComm = 0; withComm < 2; ++withComm) {
+    EquationSystem eqsys(realm, "ContinuityEQS", &cfg);
+    eqsys.solverAlgDriver_->solverAlgMap_[INTERIOR] = new AssembleContinuityEdgeSolverAlgorithm(*eqsys.linsys_, box.edges, f);
+    eqsys.solverAlgDriver_->solverConstraintAlgMap_[REF_PRESSURE] =
+      new FixPressureAtNodeAlgorithm(*eqsys.linsys_, true, 0, 0.0, box.p[0]);
+    eqsys.initialize();
+    std::vector<int> none, zero(1, 0);
+    eqsys.linsys_->setHaloPlan(none, zero, none, zero);
+    RcclComm *rc = withComm ? new RcclComm(eqsys.linsys_->handle(), comm, none, zero, zero) : nullptr;
+    eqsys.assemble_and_solve(withComm ? x1.p : x0.p);
+    hist[withComm] = eqsys.linsys_->residualHistory();
+    iters[withComm] = eqsys.linsys_->linearSolveIterations();
+    eqsys.linsys_->setComm(nullptr);
+    delete rc;
+  }
+  EXPECT_TRUE(iters[0] > 5);
+  EXPECT_EQ(iters[0], iters[1]);
+  EXPECT_TRUE(hist[0] == hist[1]);
+  const std::vector<double> a = x0.host(), b = x1.host();
+  EXPECT_TRUE(std::memcmp(a.data(), b.data(), a.size() * 8) == 0);
+  ncclCommDestroy(comm);
+}
+
 static void test_error_behaviour()
 {
   Realm realm;
@@ -523,6 +611,9 @@ int main(int argc, char **argv)
     {"ContinuityEdge.cg_jacobi", [] { test_continuity_edge_assemble_and_solve(12, "jacobi", "cg", 200); }, true},
     {"ContinuityEdge.gmres_sgs", [] { test_continuity_edge_assemble_and_solve(9, "sgs", "gmres", 90); }, true},
     {"ScalarEdge.gmres_jacobi", [] { test_scalar_edge_assemble_and_solve(10); }, true},
+    {"AdjacentAlgorithms.bit_exact", test_adjacent_algorithms, true},
+    {"RcclComm.world_1_cg", [] { test_rccl_comm_world_1("cg"); }, true},
+    {"RcclComm.world_1_gmres", [] { test_rccl_comm_world_1("gmres"); }, true},
     {"LinearSystem.errors", test_error_behaviour, true},
     {"LinearSystem.writeToFile", [&] { test_write_matrix_files(tmp); }, true},
   };

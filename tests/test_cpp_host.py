@@ -40,4 +40,4 @@ def test_cpp_host_layer_host_only():
 @pytest.mark.gpu
 def test_cpp_host_layer_against_oracle(tmp_path):
     out = _run(["--tmp", str(tmp_path)], 300)
-    assert "0 failures" in out and "7 tests" in out
+    assert "0 failures" in out and "10 tests" in out
