@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=256, help="nodes per side of each GPU's slab")
     ap.add_argument("--mode", default="rows", choices=["rows", "colored", "atomic"])
-    ap.add_argument("--cpu-n", type=int, default=128, help="box size of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-n", type=int, default=192, help="box size of the CPU baseline sample (0 = skip)")
     ap.add_argument("--variants", action="store_true", help="also time the colored/atomic scatter variants")
     ap.add_argument("--workload", default="continuity", choices=["continuity", "scalar"],
                     help="continuity = the headline Poisson step (default); scalar = BASELINE config 4: "
