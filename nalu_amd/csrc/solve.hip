@@ -866,13 +866,13 @@ __global__ __launch_bounds__(256, 3) void k_gm_upd_dots(long long n, const Solve
 template <int MULT>
 void launch_upd_dots(nalu_gpu_linsys *h, long long n, long long ld, int J, double *Hcol)
 {
-  static const bool ldsOptIn = [] {  // more than 48 KiB of dynamic LDS
+  static bool ldsOptIn[64] = {};  // more than 48 KiB of dynamic LDS: once per device
+  if (h->device >= 0 && h->device < 64 && !ldsOptIn[h->device]) {
     (void)hipFuncSetAttribute((const void *)k_gm_upd_dots<MULT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               65536);
     (void)hipGetLastError();
-    return true;
-  }();
-  (void)ldsOptIn;
+    ldsOptIn[h->device] = true;
+  }
   constexpr int TE = GM_TILE * MULT;
   const int gb = (int)std::min<long long>((n + TE - 1) / TE, GM_GRID);
   const size_t ldsBytes = sizeof(double) * (size_t)(J + 3) * TE;

@@ -264,6 +264,17 @@ def test_solve_zero_rhs_and_reuse(G, torch, oracle):
         g.solve(G.LinearSolverConfig(method="cg", preconditioner="ilut"))
     with pytest.raises(RuntimeError):
         G.LinearSolverConfig(preconditioner="bogus")
+    # max_iterations = 0: no iteration, x = x0 = 0, the true residual is ||b||
+    b = np.random.RandomState(0).uniform(-1, 1, c.m.nnodes)
+    g.set_rhs(b)
+    for method in ("cg", "gmres"):
+        g.solve(G.LinearSolverConfig(method=method, preconditioner="jacobi", max_iterations=0))
+        assert g.linearSolveIterations == 0 and not g.solution().any()
+        assert abs(g.linearResidual - np.linalg.norm(b)) <= 1e-12 * np.linalg.norm(b)
+    # kspace = 1: GMRES(1) restarts every iteration
+    g.solve(G.LinearSolverConfig(method="gmres", preconditioner="jacobi", max_iterations=7, kspace=1,
+                                 tolerance=1e-30))
+    assert g.linearSolveIterations == 7 and len(g.history) == 8
 
 
 def test_mdot_and_nodal_grad(G, torch, oracle):
