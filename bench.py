@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=256, help="nodes per side of each GPU's slab")
+    ap.add_argument("--n", "--box", dest="n", type=int, default=256, help="nodes per side of each GPU's slab")
     ap.add_argument("--mode", default="rows", choices=["rows", "colored", "atomic"])
     ap.add_argument("--cpu-n", type=int, default=192, help="box size of the CPU baseline sample (0 = skip)")
     ap.add_argument("--variants", action="store_true", help="also time the colored/atomic scatter variants")
@@ -145,10 +145,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    # NALU_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE GPU (tests);
+    # the real thing is "nccl" = RCCL, one rank per GPU
+    backend = os.environ.get("NALU_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
 
     import nalu_amd
     n = a.n
@@ -203,7 +211,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     asm_ms, asm_cnt = g.timer("assemble_edges")

@@ -36,3 +36,24 @@ def test_comm_callbacks_over_rccl_world_1(method):
     test box only world size 1 fits: it still drives every reduction of the solver through
     dist.all_reduce on the library's wrapped device buffer (no host staging)."""
     _launch(1, "gpu", method, backend="nccl")
+
+
+@pytest.mark.gpu
+def test_bench_multirank_path_rehearsal():
+    """bench.py --gpus 2 as the driver launches it, but with two ranks on the one GPU of the
+    test box over gloo (NALU_BENCH_BACKEND): partition, halo plan, callbacks, barrier / MAX
+    timing and the JSON line of the N > 1 path."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", NALU_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + (os.getpid() + 7) % 500),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--box", "48"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["config"]["nodes"] == 48 * 48 * 96 and d["config"]["solver_iterations"] == 50
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
