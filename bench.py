@@ -42,11 +42,12 @@ def box_counts(nx, ny, nz):
     return N, E, N + 2 * E
 
 
-def build_rank(n, rank, nranks, device):
+def build_rank(n, rank, nranks, device, strong=False):
     import torch
     import nalu_amd
     from nalu_amd import synth
-    S = nalu_amd.BoxSlab(n, n, n * nranks, rank, nranks, lengths=(1.0, 1.0, float(nranks)),
+    nz = n if strong else n * nranks  # strong: the n^3 box is split; weak: n^3 per GPU
+    S = nalu_amd.BoxSlab(n, n, nz, rank, nranks, lengths=(1.0, 1.0, float(nz) / n),
                          edge_order=os.environ.get("NALU_EDGE_ORDER", "slot"))
     vol, area = S.uniform_geometry()
     xyz = S.coords()
@@ -132,6 +133,8 @@ def main():
     ap.add_argument("--n", "--box", dest="n", type=int, default=256, help="nodes per side of each GPU's slab")
     ap.add_argument("--mode", default="rows", choices=["rows", "colored", "atomic"])
     ap.add_argument("--cpu-n", type=int, default=192, help="box size of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): n^3 nodes per GPU; strong: one n^3 box split over the GPUs")
     ap.add_argument("--variants", action="store_true", help="also time the colored/atomic scatter variants")
     ap.add_argument("--workload", default="continuity", choices=["continuity", "scalar"],
                     help="continuity = the headline Poisson step (default); scalar = BASELINE config 4: "
@@ -160,7 +163,8 @@ def main():
 
     import nalu_amd
     n = a.n
-    S, F, g, comm = build_rank(n, rank, world, device)
+    strong = a.scaling == "strong"
+    S, F, g, comm = build_rank(n, rank, world, device, strong)
     cfg = nalu_amd.LinearSolverConfig(method="cg", preconditioner="jacobi", tolerance=1e-5,
                                       max_iterations=50, kspace=50)
     pin = rank == 0
@@ -226,7 +230,7 @@ def main():
     spmv_bytes = 12 * nnzl + 4 * (Nl + 1) + 16 * Nl
     asm_t = asm_ms / max(asm_cnt, 1) * 1e-3
     spmv_t = spmv_ms / max(spmv_cnt, 1) * 1e-3
-    Ng, Eg, _ = box_counts(n, n, n * world)
+    Ng, Eg, _ = box_counts(n, n, n if strong else n * world)
 
     variants = {}
     if a.variants and world == 1:
@@ -251,9 +255,10 @@ def main():
             "metric": "edges assembled/s + SpMV GB/s (% HBM peak), Hex8 256^3 Poisson, 1-8 GPUs",
             "value": Eg * a.steps / dt, "unit": "edges/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"Hex8 box {n}^3 nodes per GPU ({n}x{n}x{n * world} total): " + (
+            "config": {"workload": (f"Hex8 box {n}^3 nodes split over the GPUs: " if strong else
+                                    f"Hex8 box {n}^3 nodes per GPU ({n}x{n}x{n * world} total): ") + (
                            "continuity edge assembly + pinned node + Jacobi-CG (tol 1e-5, max_it 50)"
                            if a.workload == "continuity" else
                            "scalar transport edge assembly (upwind, van Leer limiter) + mass term + "
