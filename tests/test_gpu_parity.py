@@ -573,3 +573,65 @@ def test_element_graph_27_point_rows(G, torch, oracle):
         assert g.linearSolveIterations == ref["iters"], (method, pc)
         assert np.abs(g.history - ref["history"]).max() <= TOL_SOLVE, (method, pc)
         assert rel_err(g.solution(), ref["x"]) <= 1e-9
+
+
+@pytest.mark.parametrize("seed,n,deg", [(1, 700, 6), (2, 1500, 14)])
+def test_random_unstructured_edge_graph(G, torch, oracle, seed, n, deg):
+    """An edge graph that is no lattice at all: random (L < R) edges, rows of very different
+    lengths (up to ~3x the mean degree, wider than the 8-entry SpMV chunk), random node data and
+    area vectors.  (L,R)-sorted edges keep the oracle's summation order, so the row gather and
+    SpMV are bit-exact; colored / atomic to 1e-12; the solve to 1e-10."""
+    rs = np.random.RandomState(seed)
+    L = rs.randint(0, n, n * deg // 2)
+    R = (L + 1 + rs.randint(0, n - 1, len(L))) % n
+    # a path through all nodes keeps the graph connected; drop duplicates
+    e = np.concatenate([np.stack([L, R], 1), np.stack([np.arange(n - 1), np.arange(1, n)], 1)])
+    e = np.unique(np.sort(e, axis=1), axis=0).astype(np.int32)  # sorted by (L, R), L < R
+    ne = len(e)
+    xyz = rs.uniform(0, 1, (n, 3))
+    area = rs.uniform(-1, 1, (ne, 3)) * 0.05 + 0.2 * (xyz[e[:, 1]] - xyz[e[:, 0]])  # a.dx > 0 mostly
+    area[np.abs(np.einsum("ij,ij->i", area, xyz[e[:, 1]] - xyz[e[:, 0]])) < 1e-3] += 0.1
+    dpdx, vel = rs.uniform(-1, 1, (n, 3)), rs.uniform(-1, 1, (n, 3))
+    p, rho = rs.uniform(-1, 1, n), rs.uniform(0.5, 2.0, n)
+    ls = oracle.LinSys(1, n)
+    ls.add_connections(e)
+    ls.finalize()
+    ls.zero()
+    ls.assemble_continuity(e, area, xyz, dpdx, vel, p, rho, 0.1)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+    g = G.GpuLinearSystem()
+    g.beginLinearSystemConstruction(n)
+    g.buildEdgeToNodeGraph(e)
+    g.finalizeLinearSystem()
+    assert np.diff(g.graph()[0]).max() > 8
+    for mode in ("rows", "colored", "atomic"):
+        g.zeroSystem()
+        g.assemble_continuity_edges(t(xyz.T), t(dpdx.T), t(vel.T), t(p), t(rho), t(area.T), 0.1, mode=mode)
+        g.loadComplete()
+        _compare_system(g, ls, exact=(mode == "rows"))
+    g.zeroSystem()
+    g.assemble_continuity_edges(t(xyz.T), t(dpdx.T), t(vel.T), t(p), t(rho), t(area.T), 0.1)
+    # the adjacent edge algorithms on the same graph
+    mdot = torch.empty(ne, dtype=torch.float64, device="cuda:0")
+    g.compute_mdot_edges(t(xyz.T), t(dpdx.T), t(vel.T), t(p), t(rho), t(area.T), 0.1, mdot)
+    g.synchronize()
+    assert np.array_equal(mdot.cpu().numpy(), oracle.compute_mdot(e, area, xyz, dpdx, vel, p, rho, 0.1))
+    x = rs.uniform(-1, 1, n)
+    y = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    g.spmv(t(x), y)
+    g.synchronize()
+    assert np.array_equal(y.cpu().numpy(), ls.spmv(x))
+    # make it solvable: strictly diagonally dominant values on the same graph
+    rp, ci, v = ls.owned_csr()
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    v = v.copy()
+    v[ci == rows] = np.bincount(rows, np.abs(v) * (ci != rows), n) + 1.0
+    oracle.set_values(ls, v)
+    g.set_matrix_values(v)
+    for method, pc in (("gmres", "jacobi"), ("gmres", "mt_sgs"), ("gmres", "sgs")):
+        kw = dict(tolerance=1e-11, max_iterations=100, kspace=30)
+        ref = ls.solve(method, pc, **kw)
+        g.solve(G.LinearSolverConfig(method=method, preconditioner=pc, **kw))
+        assert g.linearSolveIterations == ref["iters"], (method, pc)
+        assert np.abs(g.history - ref["history"]).max() <= TOL_SOLVE, (method, pc)
+        assert rel_err(g.solution(), ref["x"]) <= 1e-9
