@@ -247,6 +247,30 @@ def main():
             variants[mode] = dict(assemble_ms=ms / cnt, zero_ms=zms / max(cnt, 1),
                                   edges_per_s=El / ((ms + zms) / cnt * 1e-3))
             g.set_profiling(False)
+        # the un-fused scatter on its own: bulk sumInto (nalu_gpu_sum_into_batch) of precomputed
+        # per-edge 2x2 blocks + rhs pairs, i.e. what apply_coeff hands to sumInto per edge
+        t0 = time.perf_counter()
+        plan = g.createScatterPlan(S.edge_nodes)
+        plan_s = time.perf_counter() - t0
+        gen = torch.Generator(device=device).manual_seed(1)
+        blk = torch.rand(S.n_edges, 2, 2, dtype=torch.float64, device=device, generator=gen)
+        rh = torch.rand(S.n_edges, 2, dtype=torch.float64, device=device, generator=gen)
+        for mode in ("rows", "colored", "atomic"):
+            g.set_profiling(True)
+            g.reset_timers()
+            for _ in range(3):
+                g.zeroSystem()
+                g.sumIntoBatch(plan, rh, blk, mode)
+                g.loadComplete()
+            ms, cnt = g.timer("assemble_edges")
+            zms, zc = g.timer("zero")
+            variants["sum_into_batch_" + mode] = dict(
+                scatter_ms=ms / cnt, zero_ms=zms / max(cnt, 1),
+                edges_per_s=El / ((ms + zms) / cnt * 1e-3),
+                colors=plan.n_colors() if mode == "colored" else None, plan_build_s=plan_s)
+            g.set_profiling(False)
+        plan.close()
+        del blk, rh
 
     out = None
     if rank == 0:

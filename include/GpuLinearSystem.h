@@ -245,6 +245,25 @@ public:
     checkError(nalu_gpu_sum_into(h_, (int)n_obj, scratchIds.data(), rhs.data(), lhs.data()), "sumInto");
   }
 
+  // include/LinearSystem.h:80-90, the Kokkos-view overload that the reference calls per entity
+  // from inside a team loop: on the GPU the loop is the launch.  `plan` = createScatterPlan of the
+  // entities' connectivity; rhs / lhs are device arrays [n_ent][n_obj] / [n_ent][n_obj][n_obj].
+  nalu_gpu_scatter_plan *createScatterPlan(const std::vector<Entity> &entityNodes, int nodesPerEntity)
+  {
+    if (nodesPerEntity < 1 || entityNodes.size() % (size_t)nodesPerEntity)
+      throw std::runtime_error("createScatterPlan: entity list is not a multiple of nodesPerEntity");
+    nalu_gpu_scatter_plan *p = 0;
+    checkError(nalu_gpu_scatter_plan_create(h_, (int64_t)(entityNodes.size() / nodesPerEntity), nodesPerEntity,
+                                            entityNodes.data(), &p), "createScatterPlan");
+    return p;
+  }
+  void destroyScatterPlan(nalu_gpu_scatter_plan *p) { nalu_gpu_scatter_plan_destroy(p); }
+  void sumIntoBatch(nalu_gpu_scatter_plan *plan, const double *rhsDev, const double *lhsDev,
+                    int scatterMode = NALU_GPU_SCATTER_ROWS)
+  {
+    checkError(nalu_gpu_sum_into_batch(h_, plan, rhsDev, lhsDev, scatterMode), "sumInto (batch)");
+  }
+
   // include/LinearSystem.h:101-106: the nodes of `parts`, fields on the device
   void applyDirichletBCs(const double *solutionField, const double *bcValuesField, const EntityVector &nodes,
                          const unsigned beginPos, const unsigned endPos)

@@ -94,9 +94,29 @@ int nalu_gpu_set_rhs(nalu_gpu_linsys *h, const double *rhs /* n_rows */);
 int nalu_gpu_zero_system(nalu_gpu_linsys *h);
 /* sumInto, vector overload (src/TpetraLinearSystem.C:1454-1507 + sum_into_row :1350-1385):
  * host slow path for nodal / BC algorithms. lhs is n_obj x n_obj row-major.  Rows of
- * non-owned nodes and columns outside the graph are skipped silently, as there. */
+ * non-owned nodes are skipped (their owner assembles them).  A column that is not in a row is
+ * skipped silently together with every larger column of the call, exactly as the single
+ * ascending pass of sum_into_row (:1363-1383) does. */
 int nalu_gpu_sum_into(nalu_gpu_linsys *h, int n_obj, const int *node_lids, const double *rhs,
                       const double *lhs);
+
+/* sumInto, Kokkos-view overload (src/TpetraLinearSystem.C:1387-1452), which the reference
+ * calls from inside a team loop over entities: here the loop is the launch.  A plan holds the
+ * entity -> matrix-slot search of sum_into_row (:1350-1385) for one connectivity
+ * (ent_lids[n_ent][n_obj], host, local node ids; edges n_obj = 2, Hex8 elements 8, nodes 1);
+ * nalu_gpu_sum_into_batch then adds lhs_dev[n_ent][n_obj][n_obj] (row-major blocks) and
+ * rhs_dev[n_ent][n_obj] of every entity.  NALU_GPU_SCATTER_ROWS adds in ascending entity order
+ * per value (bit-identical to the sequential entity loop), _COLORED in entity-colour order,
+ * _ATOMIC in any order.  Rows of non-owned nodes and columns outside the graph are skipped as
+ * in nalu_gpu_sum_into; an entity that lists a node twice is rejected. */
+typedef struct nalu_gpu_scatter_plan nalu_gpu_scatter_plan;
+int nalu_gpu_scatter_plan_create(nalu_gpu_linsys *h, int64_t n_ent, int n_obj, const int *ent_lids,
+                                 nalu_gpu_scatter_plan **out);
+int nalu_gpu_scatter_plan_destroy(nalu_gpu_scatter_plan *p);
+/* number of entity colours of the COLORED mode (computed on first use) */
+int nalu_gpu_scatter_plan_colors(nalu_gpu_scatter_plan *p, int *n_colors);
+int nalu_gpu_sum_into_batch(nalu_gpu_linsys *h, nalu_gpu_scatter_plan *p, const double *rhs_dev,
+                            const double *lhs_dev, int scatter_mode);
 
 typedef struct { const double *x, *y, *z; } nalu_gpu_vec3; /* SoA device arrays */
 

@@ -20,7 +20,9 @@ SYMBOLS = [
     "nalu_gpu_build_dirichlet_node_graph", "nalu_gpu_finalize", "nalu_gpu_get_sizes",
     "nalu_gpu_get_graph", "nalu_gpu_get_matrix_values", "nalu_gpu_get_rhs",
     "nalu_gpu_get_solution", "nalu_gpu_set_matrix_values", "nalu_gpu_set_rhs",
-    "nalu_gpu_zero_system", "nalu_gpu_sum_into", "nalu_gpu_assemble_continuity_edges",
+    "nalu_gpu_zero_system", "nalu_gpu_sum_into", "nalu_gpu_scatter_plan_create",
+    "nalu_gpu_scatter_plan_destroy", "nalu_gpu_scatter_plan_colors", "nalu_gpu_sum_into_batch",
+    "nalu_gpu_assemble_continuity_edges",
     "nalu_gpu_assemble_scalar_edges", "nalu_gpu_assemble_scalar_mass_be",
     "nalu_gpu_apply_dirichlet", "nalu_gpu_reset_rows", "nalu_gpu_load_complete",
     "nalu_gpu_solve", "nalu_gpu_spmv", "nalu_gpu_dot", "nalu_gpu_axpy", "nalu_gpu_norm2",
@@ -115,6 +117,10 @@ def load():
         "nalu_gpu_set_rhs": [vp, vp],
         "nalu_gpu_zero_system": [vp],
         "nalu_gpu_sum_into": [vp, ci, vp, vp, vp],
+        "nalu_gpu_scatter_plan_create": [vp, i64, ci, vp, P(vp)],
+        "nalu_gpu_scatter_plan_destroy": [vp],
+        "nalu_gpu_scatter_plan_colors": [vp, P(ci)],
+        "nalu_gpu_sum_into_batch": [vp, vp, vp, vp, ci],
         "nalu_gpu_assemble_continuity_edges": [vp, P(ContinuityFields), dbl, dbl, dbl, dbl, ci],
         "nalu_gpu_assemble_scalar_edges": [vp, P(ScalarFields), P(ScalarOptions), ci],
         "nalu_gpu_assemble_scalar_mass_be": [vp, vp, vp, vp, vp, vp, dbl],

@@ -818,11 +818,17 @@ extern "C" int nalu_gpu_sum_into(nalu_gpu_linsys *h, int n_obj, const int *node_
     if (row >= h->nOwned) continue;
     const int64_t b = h->rowPtr[row], e = h->rowPtr[row + 1];
     const long long off = h->hSliceOff[row / SELL_C];
-    for (int j = 0; j < n_obj; ++j) {
+    // sum_into_row (:1363-1383) passes once through the row with the columns in ascending
+    // order: a column that is not in the row runs the scan to the row's end, so that column
+    // AND every larger one of this call are dropped -- reproduced here
+    int order[8];
+    for (int j = 0; j < n_obj; ++j) order[j] = j;
+    std::sort(order, order + n_obj, [&](int x, int y) { return node_lids[x] < node_lids[y]; });
+    for (int jj = 0; jj < n_obj; ++jj) {
+      const int j = order[jj];
       const int *it = std::lower_bound(&h->colIdx[b], &h->colIdx[b] + (e - b), node_lids[j]);
-      if (it == &h->colIdx[b] + (e - b) || *it != node_lids[j]) continue;
+      if (it == &h->colIdx[b] + (e - b) || *it != node_lids[j]) break;
       const int k = (int)(it - &h->colIdx[b]);
-      // duplicate entities in one call accumulate, as the sorted scan would
       a.pos[a.nPos] = off + (long long)k * SELL_C + row % SELL_C;
       a.val[a.nPos] = lhs[i * n_obj + j];
       ++a.nPos;

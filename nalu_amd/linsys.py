@@ -63,6 +63,35 @@ class LinearSolverConfig:
                               self.max_iterations, self.kspace, self.check_every)
 
 
+class ScatterPlan:
+    """nalu_gpu_scatter_plan: entity -> matrix-slot map of one connectivity."""
+
+    def __init__(self, owner, ent_lids):
+        a = _np(ent_lids, np.int32)
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        self.owner, self.n_ent, self.n_obj = owner, a.shape[0], a.shape[1]
+        self.p = C.c_void_p()
+        L.check(owner.lib.nalu_gpu_scatter_plan_create(owner.h, self.n_ent, self.n_obj,
+                                                       a.ctypes.data, C.byref(self.p)))
+
+    def n_colors(self):
+        n = C.c_int()
+        L.check(self.owner.lib.nalu_gpu_scatter_plan_colors(self.p, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self.p and self.owner.h:
+            self.owner.lib.nalu_gpu_scatter_plan_destroy(self.p)
+        self.p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class GpuLinearSystem:
     """One sierra::nalu::LinearSystem on one GPU."""
 
@@ -228,6 +257,20 @@ class GpuLinearSystem:
         assert r.size == ids.size and m.size == ids.size ** 2
         L.check(self.lib.nalu_gpu_sum_into(self.h, len(ids), ids.ctypes.data, r.ctypes.data,
                                            m.ctypes.data))
+
+    def createScatterPlan(self, ent_lids):
+        """Plan of the bulk sumInto for one connectivity: ent_lids (n_ent, n_obj) local ids."""
+        return ScatterPlan(self, ent_lids)
+
+    def sumIntoBatch(self, plan, rhs, lhs, mode="rows"):
+        """sumInto (view overload, src/TpetraLinearSystem.C:1387-1452) of all entities of the
+        plan: device tensors rhs (n_ent, n_obj) and lhs (n_ent, n_obj, n_obj)."""
+        assert plan.owner is self
+        assert rhs.numel() == plan.n_ent * plan.n_obj and rhs.is_contiguous()
+        assert lhs.numel() == plan.n_ent * plan.n_obj ** 2 and lhs.is_contiguous()
+        assert rhs.element_size() == 8 and lhs.element_size() == 8
+        L.check(self.lib.nalu_gpu_sum_into_batch(self.h, plan.p, _ptr(rhs), _ptr(lhs),
+                                                 L.SCATTER[mode]))
 
     def assemble_continuity_edges(self, coords, dpdx, vel, pressure, density, edge_area, dt,
                                   gamma1=1.0, noc=1.0, interp_together=1.0, mode="rows"):

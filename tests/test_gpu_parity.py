@@ -635,3 +635,120 @@ def test_random_unstructured_edge_graph(G, torch, oracle, seed, n, deg):
         assert g.linearSolveIterations == ref["iters"], (method, pc)
         assert np.abs(g.history - ref["history"]).max() <= TOL_SOLVE, (method, pc)
         assert rel_err(g.solution(), ref["x"]) <= 1e-9
+
+
+def test_bulk_sum_into_tpetra_gold(G, torch, oracle):
+    """The gold 12x12 matrix of unit_tests/UnitTestTpetra.C:101-114 through the bulk device
+    sumInto (one call for both elements) instead of one host sumInto per element."""
+    m = oracle.BoxMesh(2, 2, 3)
+    g = G.GpuLinearSystem()
+    g.beginLinearSystemConstruction(12)
+    g.buildElemToNodeGraph(m.hex_nodes)
+    g.finalizeLinearSystem()
+    plan = g.createScatterPlan(m.hex_nodes)
+    lhs = torch.as_tensor(np.stack([ELEM_VALS, ELEM_VALS]), dtype=torch.float64, device="cuda:0").contiguous()
+    rhs = torch.zeros(2, 8, dtype=torch.float64, device="cuda:0")
+    rp, ci = g.graph()
+    for mode in ("rows", "colored", "atomic"):
+        g.zeroSystem()
+        g.sumIntoBatch(plan, rhs, lhs, mode)
+        g.loadComplete()
+        np.testing.assert_allclose(dense(rp, ci, g.matrix_values(), 12), LHS_VALS, atol=1e-9, rtol=0)
+    assert plan.n_colors() == 2  # the two hexes share a face
+    plan.close()
+
+
+@pytest.mark.parametrize("n_owned_frac", [1.0, 0.6])
+def test_bulk_sum_into_elements(G, torch, oracle, n_owned_frac):
+    """Random 8x8 blocks + rhs of every Hex8 element: ROWS is bit-identical to the oracle's
+    sequential per-element sumInto (src/TpetraLinearSystem.C:1454-1507), COLORED / ATOMIC agree
+    to 1e-12; a second call adds; rows of non-owned nodes are skipped (their owner assembles
+    them); a nodal (n_obj = 1) plan on the same system adds to the diagonal."""
+    m = oracle.BoxMesh(7, 6, 5)
+    n = m.nnodes
+    n_owned = int(n * n_owned_frac)
+    rs = np.random.RandomState(5)
+    ne = len(m.hex_nodes)
+    lhs, rhs = rs.uniform(-1, 1, (ne, 8, 8)), rs.uniform(-1, 1, (ne, 8))
+    nl, nr = rs.uniform(1, 2, (n, 1, 1)), rs.uniform(-1, 1, (n, 1))
+    ls = oracle.LinSys(1, n_owned, n - n_owned)
+    ls.add_connections(m.hex_nodes)
+    ls.finalize()
+    ls.zero()
+    for rep in range(2):
+        for e in range(ne):
+            ls.sum_into(m.hex_nodes[e], rhs[e], lhs[e])
+    for i in range(n):
+        ls.sum_into([i], nr[i], nl[i])
+    g = G.GpuLinearSystem()
+    g.beginLinearSystemConstruction(n_owned, n - n_owned, 0, owners=[0] * n_owned + [1] * (n - n_owned))
+    g.buildElemToNodeGraph(m.hex_nodes)
+    g.finalizeLinearSystem()
+    plan, nodal = g.createScatterPlan(m.hex_nodes), g.createScatterPlan(np.arange(n))
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+    dl, dr, dnl, dnr = t(lhs), t(rhs), t(nl), t(nr)
+    for mode in ("rows", "colored", "atomic"):
+        g.zeroSystem()
+        g.sumIntoBatch(plan, dr, dl, mode)
+        g.sumIntoBatch(plan, dr, dl, mode)
+        g.sumIntoBatch(nodal, dnr, dnl, mode)
+        g.loadComplete()
+        _compare_system(g, ls, exact=(mode == "rows"))
+    assert plan.n_colors() == 8
+    # an empty plan is a no-op; a node listed twice in one entity is rejected loudly
+    empty = g.createScatterPlan(np.zeros((0, 8), np.int32))
+    g.sumIntoBatch(empty, t(np.zeros((0, 8))), t(np.zeros((0, 8, 8))))
+    with pytest.raises(G.NaluGpuError, match="twice"):
+        g.createScatterPlan([[0, 1, 1]])
+    other = G.GpuLinearSystem()
+    other.beginLinearSystemConstruction(4)
+    other.buildNodeGraph(np.arange(4))
+    other.finalizeLinearSystem()
+    with pytest.raises(G.NaluGpuError, match="another"):
+        other.sumIntoBatch.__func__(other, _Borrowed(plan, other), dr, dl)
+
+
+class _Borrowed:
+    """a plan presented to the wrong linear system (the wrapper's own assert is bypassed)"""
+
+    def __init__(self, plan, owner):
+        self.p, self.n_ent, self.n_obj, self.owner = plan.p, plan.n_ent, plan.n_obj, owner
+
+
+def test_bulk_sum_into_edges_equals_fused_kernel(G, torch, oracle):
+    """Per-edge 2x2 coefficients computed by the oracle (the reference's apply_coeff inputs,
+    src/AssembleContinuityEdgeSolverAlgorithm.C:189-205) scattered by the bulk sumInto give the
+    same system, bit for bit, as the fused device edge kernel and as the oracle's edge loop;
+    columns outside the graph are dropped silently."""
+    c = Case(oracle, 11, 0.125)
+    d = c.dev(torch)
+    ls = c.oracle_continuity()
+    lhs, rhs = oracle.continuity_edge_coeffs(c.m.edge_nodes, c.area, c.m.xyz, c.dpdx, c.vel, c.p,
+                                             c.rho, c.dt)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+    g = c.gpu_system(G.GpuLinearSystem)
+    plan = g.createScatterPlan(c.m.edge_nodes)
+    for mode in ("rows", "colored", "atomic"):
+        g.zeroSystem()
+        g.sumIntoBatch(plan, t(rhs), t(lhs), mode)
+        g.loadComplete()
+        _compare_system(g, ls, exact=(mode == "rows"))
+    fused = c.gpu_system(G.GpuLinearSystem)
+    fused.assemble_continuity_edges(d["coords"], d["dpdx"], d["vel"], d["p"], d["rho"], d["area"], c.dt)
+    g.zeroSystem()
+    g.sumIntoBatch(plan, t(rhs), t(lhs))
+    assert np.array_equal(g.matrix_values(), fused.matrix_values())
+    assert np.array_equal(g.rhs(), fused.rhs())
+    # pairs of nodes that share no edge: sum_into_row's single ascending pass (:1363-1383) adds
+    # the diagonal of the lower node only -- in the higher node's row the missing (lower) column
+    # runs the scan to the end, so its diagonal is dropped too.  Host and bulk path reproduce it.
+    far = np.stack([np.arange(0, 50), np.arange(600, 650)], 1)
+    blocks, r2 = np.tile([[1.0, 7.0], [9.0, 2.0]], (50, 1, 1)), np.ones((50, 2))
+    for e in range(50):
+        ls.sum_into(far[e], r2[e], blocks[e])
+    g.sumIntoBatch(g.createScatterPlan(far), t(r2), t(blocks))
+    _compare_system(g, ls, exact=True)
+    for e in range(50):
+        ls.sum_into(far[e][::-1], r2[e], blocks[e])
+        g.sumInto(far[e][::-1], r2[e], blocks[e])
+    _compare_system(g, ls, exact=True)
