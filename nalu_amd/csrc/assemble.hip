@@ -294,6 +294,147 @@ __global__ __launch_bounds__(SELL_C) void k_assemble_rows(SellView A, typename O
   else rhs[row] += b;
 }
 
+// Entry-parallel row gather, persistent: a workgroup of NW waves assembles one QUARTER slice
+// (64 rows) per iteration; wave k evaluates the k-th entry of those 64 rows (for w > NW:
+// entries k, k + NW, ...), so the loads of a row's edges -- edge data and out-of-quarter
+// neighbours -- are all in flight at once instead of one dependent round trip per entry,
+// without one thread having to hold them in registers.  For the same number of resident waves
+// the rows in flight per XCD shrink ~NW-fold, and the neighbour lines gathered by adjacent
+// slices are still in the 4 MiB L2 when they are asked for again (DESIGN.md section 3:
+// FETCH_SIZE 6.1 -> 3.9 GB per launch at 256^3).  The workgroups are persistent (one launch
+// overhead and one argument fetch per workgroup, the next quarter's slice metadata requested
+// while the current one computes) and walk the quarters in the XCD-aware order of the row
+// kernels.  The quarter's own nodal data goes through LDS (each wave fetches 1-2 of its
+// fields); every wave leaves its rows' shares of diagonal and rhs in LDS and the last wave adds
+// them in entry order: the same additions in the same order as k_assemble_rows, bit for bit.
+constexpr int QROWS = 64;
+template <class Op, bool SET, int NW, int WMAX>
+__global__ __launch_bounds__(QROWS * NW) void k_assemble_entries(SellView A, typename Op::Params P,
+                                                                  double *__restrict__ rhs)
+{
+  using Node = typename Op::Node;
+  using Edge = typename Op::Edge;
+  constexpr int NF = sizeof(Node) / sizeof(double);
+  constexpr int QPS = SELL_C / QROWS;  // quarters per slice
+  __shared__ double ldsOwn[NF * QROWS];
+  __shared__ double ldsD[2][WMAX * QROWS], ldsB[2][WMAX * QROWS];
+  __shared__ unsigned char ldsKind[2][WMAX * QROWS];  // 0 nothing, 1 edge share, 2 the diagonal
+  const int nQuarters = A.nSlices * QPS;
+  const int lane = threadIdx.x & (QROWS - 1), wave = threadIdx.x / QROWS;
+  const double *const *fp = reinterpret_cast<const double *const *>(&P.f);
+  int buf = 0;
+  for (int t = blockIdx.x; t < nQuarters; t += gridDim.x, buf ^= 1) {
+    const int qid = xcd_run(t, nQuarters, A.xcdRun * QPS);
+    const int slice = qid / QPS, q = qid % QPS;
+    const int qBase = slice * SELL_C + q * QROWS;
+    const int row = qBase + lane;
+    const bool live = row < A.nRows;
+    const int nLive = min(QROWS, A.nRows - qBase);  // <= 0: the quarter is beyond the matrix
+    const long long off = A.sliceOff[slice];
+    const int w = A.sliceWidth[slice];
+    const int *kOff = A.kOff + off / SELL_C;
+    const unsigned *tBase = A.tBase + off / SELL_C, *tMul = A.tMul + off / SELL_C;
+    bool ex = false, exT = false;
+    if (live) {
+      ex = (A.exMask[(size_t)slice * 4 + q] >> lane) & 1ULL;
+      exT = (A.exMaskT[(size_t)slice * 4 + q] >> lane) & 1ULL;
+    }
+    // first entry of this wave: decode and request everything it needs from memory
+    int k = wave;
+    unsigned tag = TAG_PAD;
+    int c = row;
+    long long pos = 0;
+    bool isEdge = false, inQ = false;
+    Edge E;
+    Node nb;
+    if (live && k < w) {
+      pos = off + (long long)k * SELL_C + q * QROWS + lane;
+      tag = exT ? A.tags[pos] : tBase[k] + tMul[k] * (unsigned)row;
+      isEdge = tag < TAG_OTHER;
+      if (isEdge) {
+        c = ex ? A.cols[pos] : row + kOff[k];
+        inQ = (unsigned)(c - qBase) < (unsigned)nLive;
+        E = Op::load_edge(P, (long long)(tag & 0x7FFFFFFFu));
+        if (!inQ) nb = Op::load(P, c);
+      }
+    }
+    // the quarter's own nodal data: wave v fetches fields v, v + NW, ...
+    if (live) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+        if (f % NW == wave) ldsOwn[f * QROWS + lane] = fp[f][row];
+    }
+    __syncthreads();
+    for (; k < w; k += NW) {
+      if (k != wave) {  // entries beyond the first (slices wider than NW): one round trip each
+        tag = TAG_PAD;
+        isEdge = inQ = false;
+        if (live) {
+          pos = off + (long long)k * SELL_C + q * QROWS + lane;
+          tag = exT ? A.tags[pos] : tBase[k] + tMul[k] * (unsigned)row;
+          isEdge = tag < TAG_OTHER;
+          if (isEdge) {
+            c = ex ? A.cols[pos] : row + kOff[k];
+            inQ = (unsigned)(c - qBase) < (unsigned)nLive;
+            E = Op::load_edge(P, (long long)(tag & 0x7FFFFFFFu));
+            if (!inQ) nb = Op::load(P, c);
+          }
+        }
+      }
+      unsigned char kind = 0;
+      if (live) {
+        if (isEdge) {
+          Node own;
+          double *po = reinterpret_cast<double *>(&own);
+#pragma unroll
+          for (int f = 0; f < NF; ++f) po[f] = ldsOwn[f * QROWS + lane];
+          if (inQ) {
+            double *pn = reinterpret_cast<double *>(&nb);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) pn[f] = ldsOwn[f * QROWS + (c - qBase)];
+          }
+          const bool isR = (tag >> 31) != 0;
+          double lhs[4], rh[2];
+          Op::edge(P, E, select(isR, nb, own), select(isR, own, nb), lhs, rh);
+          const double offd = isR ? lhs[2] : lhs[1];
+          if (SET) A.vals[pos] = offd;
+          else A.vals[pos] += offd;
+          ldsD[buf][k * QROWS + lane] = isR ? lhs[3] : lhs[0];
+          ldsB[buf][k * QROWS + lane] = isR ? rh[1] : rh[0];
+          kind = 1;
+        } else if (tag == TAG_DIAG) {
+          kind = 2;
+        } else if (SET) {
+          A.vals[pos] = 0.0;
+        }
+      }
+      ldsKind[buf][k * QROWS + lane] = kind;
+    }
+    // after this barrier ldsOwn may be overwritten (next iteration) and the shares of `buf` are
+    // complete; they are next written two iterations on, behind two more barriers
+    __syncthreads();
+    if (wave == NW - 1 && live) {
+      double diag = 0.0, b = 0.0;
+      long long diagPos = -1;
+      for (int kk = 0; kk < w; ++kk) {
+        const unsigned char kind = ldsKind[buf][kk * QROWS + lane];
+        if (kind == 1) {
+          diag += ldsD[buf][kk * QROWS + lane];
+          b += ldsB[buf][kk * QROWS + lane];
+        } else if (kind == 2) {
+          diagPos = off + (long long)kk * SELL_C + q * QROWS + lane;
+        }
+      }
+      if (diagPos >= 0) {
+        if (SET) A.vals[diagPos] = diag;
+        else A.vals[diagPos] += diag;
+      }
+      if (SET) rhs[row] = b;
+      else rhs[row] += b;
+    }
+  }
+}
+
 __device__ __forceinline__ void add_plain(double *p, double v) { *p += v; }
 __device__ __forceinline__ void add_atomic(double *p, double v) { unsafeAtomicAdd(p, v); }
 
@@ -338,8 +479,25 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
   if (mode == NALU_GPU_SCATTER_ROWS) {
     const bool set = h->lazyZero;
     h->lazyZero = false;
+    // NG_ASM_ENTRIES=1 selects the entry-parallel persistent kernel (slices of up to 32
+    // entries) instead of the row kernel: 1.6x less HBM traffic but latency-bound and 2x slower
+    // as it stands, kept as the starting point for a pipelined version.
+    // Grid = what fits the chip at once, a multiple of 8 so that a workgroup stays on its XCD's
+    // share of the schedule.
+    const bool entries = getenv("NG_ASM_ENTRIES") && atoi(getenv("NG_ASM_ENTRIES")) != 0;
+    const int nQ = h->nSlices * (SELL_C / QROWS);
     timer_begin(h, NALU_GPU_T_ASSEMBLE_EDGES);
-    if (set) k_assemble_rows<Op, true><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), P, h->dRhs);
+    if (entries && h->maxSliceWidth <= 32) {
+      void (*kern)(SellView, typename Op::Params, double *) =
+          h->maxSliceWidth <= 8 ? (set ? k_assemble_entries<Op, true, 8, 8> : k_assemble_entries<Op, false, 8, 8>)
+                                : (set ? k_assemble_entries<Op, true, 8, 32> : k_assemble_entries<Op, false, 8, 32>);
+      int perCu = 0, cus = 0;
+      NG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kern, QROWS * 8, 0));
+      NG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+      int grid = std::max(1, perCu) * std::max(1, cus);
+      grid = std::min((grid + 7) / 8 * 8, (nQ + 7) / 8 * 8);
+      kern<<<grid, QROWS * 8, 0, h->stream>>>(sell_view(h), P, h->dRhs);
+    } else if (set) k_assemble_rows<Op, true><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), P, h->dRhs);
     else k_assemble_rows<Op, false><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), P, h->dRhs);
     timer_end(h, NALU_GPU_T_ASSEMBLE_EDGES);
     NG_HIP(hipGetLastError());

@@ -458,6 +458,7 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
     const int r1 = std::min(nO, (s + 1) * SELL_C);
     for (int r = s * SELL_C; r < r1; ++r) w = std::max(w, len[r]);
     h->hSliceWidth[s] = w;
+    h->maxSliceWidth = std::max(h->maxSliceWidth, w);
     h->hSliceOff[s + 1] = h->hSliceOff[s] + (long long)w * SELL_C;
   }
   h->sellSize = h->hSliceOff[h->nSlices];

@@ -98,6 +98,7 @@ struct nalu_gpu_linsys {
   std::vector<long long> hSliceOff;
   std::vector<int> hSliceWidth;
   long long sellSize = 0;
+  int maxSliceWidth = 0;
   long long *dSliceOff = nullptr;
   int *dSliceWidth = nullptr;
   int *dCols = nullptr;

@@ -752,3 +752,68 @@ def test_bulk_sum_into_edges_equals_fused_kernel(G, torch, oracle):
         ls.sum_into(far[e][::-1], r2[e], blocks[e])
         g.sumInto(far[e][::-1], r2[e], blocks[e])
     _compare_system(g, ls, exact=True)
+
+
+def test_entry_parallel_assembly_kernel(G, torch, oracle, monkeypatch):
+    """NG_ASM_ENTRIES=1: the persistent entry-parallel variant of the row gather (one wave per
+    matrix entry of 64 rows, ordered sum of the diagonal / rhs shares through LDS) gives the
+    oracle's matrix and rhs bit for bit, like the row kernel: continuity and scalar operators,
+    a perturbed box, a ragged sliver, the 27-point element graph (slices wider than 8 entries)
+    and an unstructured graph (rows of ~20 entries, flagged slices)."""
+    monkeypatch.setenv("NG_ASM_ENTRIES", "1")
+    for dims, perturb in (((20, 20, 20), 0.125), ((2, 3, 70), 0.0), ((67, 5, 9), 0.125)):
+        c = Case(oracle, 0, perturb, dims=dims)
+        d = c.dev(torch)
+        g = c.gpu_system(G.GpuLinearSystem)
+        g.assemble_continuity_edges(d["coords"], d["dpdx"], d["vel"], d["p"], d["rho"], d["area"], c.dt)
+        _compare_system(g, c.oracle_continuity(), exact=True)
+        # second call on the same system adds (SET = false path; the shares of a row are summed
+        # before they are added to the old value, as in the row kernel: 1e-12, not bit-exact)
+        g.assemble_scalar_edges(d["coords"], d["dqdx"], d["vel"], d["q"], d["rho"], d["gamma"],
+                                d["area"], d["mdot"], hybrid_factor=1.0, limiter=True)
+        ls = c.oracle_continuity()
+        ls.assemble_scalar(c.m.edge_nodes, c.area, c.mdot, c.m.xyz, c.dqdx, c.vel, c.q, c.rho,
+                           c.gamma, oracle.scalar_opts(hybrid_factor=1.0, limiter=True))
+        _compare_system(g, ls, exact=False)
+    # edges on top of an element graph: rows of up to 27 entries, most of them not edges
+    c = Case(oracle, 0, 0.125, dims=(7, 6, 5))
+    d = c.dev(torch)
+    ls = oracle.LinSys(1, c.m.nnodes)
+    ls.add_connections(c.m.hex_nodes)
+    ls.add_connections(c.m.edge_nodes)
+    ls.finalize()
+    ls.zero()
+    ls.assemble_continuity(c.m.edge_nodes, c.area, c.m.xyz, c.dpdx, c.vel, c.p, c.rho, c.dt)
+    g = G.GpuLinearSystem()
+    g.beginLinearSystemConstruction(c.m.nnodes)
+    g.buildElemToNodeGraph(c.m.hex_nodes)
+    g.buildEdgeToNodeGraph(c.m.edge_nodes)
+    g.finalizeLinearSystem()
+    g.zeroSystem()
+    g.assemble_continuity_edges(d["coords"], d["dpdx"], d["vel"], d["p"], d["rho"], d["area"], c.dt)
+    _compare_system(g, ls, exact=True)
+    # unstructured
+    rs = np.random.RandomState(3)
+    n = 900
+    L = rs.randint(0, n, n * 5)
+    R = (L + 1 + rs.randint(0, n - 1, len(L))) % n
+    e = np.unique(np.sort(np.stack([L, R], 1), axis=1), axis=0).astype(np.int32)
+    xyz = rs.uniform(0, 1, (n, 3))
+    area = rs.uniform(-1, 1, (len(e), 3)) * 0.05 + 0.2 * (xyz[e[:, 1]] - xyz[e[:, 0]])
+    area[np.abs(np.einsum("ij,ij->i", area, xyz[e[:, 1]] - xyz[e[:, 0]])) < 1e-3] += 0.1
+    dpdx, vel = rs.uniform(-1, 1, (n, 3)), rs.uniform(-1, 1, (n, 3))
+    p, rho = rs.uniform(-1, 1, n), rs.uniform(0.5, 2.0, n)
+    ls = oracle.LinSys(1, n)
+    ls.add_connections(e)
+    ls.finalize()
+    ls.zero()
+    ls.assemble_continuity(e, area, xyz, dpdx, vel, p, rho, 0.1)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+    g = G.GpuLinearSystem()
+    g.beginLinearSystemConstruction(n)
+    g.buildEdgeToNodeGraph(e)
+    g.finalizeLinearSystem()
+    assert 8 < np.diff(g.graph()[0]).max() <= 32
+    g.zeroSystem()
+    g.assemble_continuity_edges(t(xyz.T), t(dpdx.T), t(vel.T), t(p), t(rho), t(area.T), 0.1)
+    _compare_system(g, ls, exact=True)
