@@ -216,6 +216,18 @@ public:
     checkError(nalu_gpu_build_dirichlet_node_graph(h_, (int64_t)nodes.size(), nodes.data()),
                "buildDirichletNodeGraph");
   }
+  // src/TpetraLinearSystem.C:157-160 (simple case of getDofStatus_impl, :2148-2157)
+  int getDofStatus(Entity node)
+  {
+    int st = 0;
+    int rc = nalu_gpu_get_dof_status(h_, 1, &node, &st);
+    if (rc == NALU_GPU_ESTATE) {  // nothing built yet: the node counts are not registered
+      beginLinearSystemConstruction();
+      rc = nalu_gpu_get_dof_status(h_, 1, &node, &st);
+    }
+    checkError(rc, "getDofStatus");
+    return st;
+  }
   void finalizeLinearSystem()
   {
     if (!inConstruction_) throw std::runtime_error("finalizeLinearSystem: no graph was built");

@@ -60,6 +60,14 @@ int nalu_gpu_destroy(nalu_gpu_linsys *h);
  * n_owned+n_shared+n_ghost entries in local order; the ordering rules above are checked. */
 int nalu_gpu_begin_construction(nalu_gpu_linsys *h, int n_owned, int n_shared, int n_ghost,
                                 const int64_t *gids, const int *owner_ranks, int my_rank);
+/* getDofStatus (src/TpetraLinearSystem.C:157-160 -> getDofStatus_impl :2111-2157, the "simple
+ * case": no periodic / non-conformal parts): DofStatus of include/TpetraLinearSystem.h:49-55 for
+ * n local nodes.  Valid once begin_construction has been called. */
+enum {
+  NALU_GPU_DS_NotSet = 0, NALU_GPU_DS_SkippedDOF = 1 << 1, NALU_GPU_DS_OwnedDOF = 1 << 2,
+  NALU_GPU_DS_SharedNotOwnedDOF = 1 << 3, NALU_GPU_DS_GhostedDOF = 1 << 4
+};
+int nalu_gpu_get_dof_status(nalu_gpu_linsys *h, int64_t n_nodes, const int *node_lids, int *status);
 /* buildNodeGraph (src/TpetraLinearSystem.C:373-395) */
 int nalu_gpu_build_node_graph(nalu_gpu_linsys *h, int64_t n_nodes, const int *node_lids);
 /* buildEdgeToNodeGraph (src/TpetraLinearSystem.C:420-425 -> :397-418 -> addConnections

@@ -10,12 +10,14 @@ SCATTER = {"rows": 0, "colored": 1, "atomic": 2}
 METHOD = {"cg": 0, "gmres": 1}
 PRECOND = {"none": 0, "jacobi": 1, "default": 1, "sgs": 2, "chebyshev": 3, "mt_sgs": 4}
 PECLET = {"classic": 0, "tanh": 1}
+# DofStatus (include/TpetraLinearSystem.h:49-55)
+DS_NotSet, DS_SkippedDOF, DS_OwnedDOF, DS_SharedNotOwnedDOF, DS_GhostedDOF = 0, 2, 4, 8, 16
 TIMERS = {"zero": 0, "assemble_edges": 1, "spmv": 2, "solve": 3, "precond": 4, "bc": 5}
 
 # every symbol include/nalu_gpu.h declares (tests check the library exports them all)
 SYMBOLS = [
     "nalu_gpu_last_error", "nalu_gpu_version", "nalu_gpu_create", "nalu_gpu_destroy",
-    "nalu_gpu_begin_construction", "nalu_gpu_build_node_graph",
+    "nalu_gpu_begin_construction", "nalu_gpu_get_dof_status", "nalu_gpu_build_node_graph",
     "nalu_gpu_build_edge_to_node_graph", "nalu_gpu_build_elem_to_node_graph",
     "nalu_gpu_build_dirichlet_node_graph", "nalu_gpu_finalize", "nalu_gpu_get_sizes",
     "nalu_gpu_get_graph", "nalu_gpu_get_matrix_values", "nalu_gpu_get_rhs",
@@ -103,6 +105,7 @@ def load():
         "nalu_gpu_create": [P(vp), ci, ci, vp],
         "nalu_gpu_destroy": [vp],
         "nalu_gpu_begin_construction": [vp, ci, ci, ci, vp, vp, ci],
+        "nalu_gpu_get_dof_status": [vp, i64, vp, vp],
         "nalu_gpu_build_node_graph": [vp, i64, vp],
         "nalu_gpu_build_edge_to_node_graph": [vp, i64, vp],
         "nalu_gpu_build_elem_to_node_graph": [vp, i64, ci, vp],

@@ -202,6 +202,22 @@ extern "C" int nalu_gpu_begin_construction(nalu_gpu_linsys *h, int n_owned, int 
   return NALU_GPU_OK;
 }
 
+extern "C" int nalu_gpu_get_dof_status(nalu_gpu_linsys *h, int64_t n, const int *lids, int *status)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  NG_REQUIRE(h->state >= 1, NALU_GPU_ESTATE, "getDofStatus needs begin_construction first");
+  NG_REQUIRE(n >= 0 && (n == 0 || (lids && status)), NALU_GPU_EINVAL, "bad node list");
+  for (int64_t i = 0; i < n; ++i) {
+    NG_REQUIRE(lids[i] >= 0 && lids[i] < h->nCols, NALU_GPU_EINVAL,
+               "local node %d outside [0,%d)", lids[i], h->nCols);
+    // the local numbering is owned | shared-not-owned | ghosted (begin_construction)
+    status[i] = lids[i] < h->nOwned ? NALU_GPU_DS_OwnedDOF
+              : lids[i] < h->nOwned + h->nShared ? NALU_GPU_DS_SharedNotOwnedDOF
+                                                 : NALU_GPU_DS_GhostedDOF;
+  }
+  return NALU_GPU_OK;
+}
+
 static int add_block(nalu_gpu_linsys *h, int64_t n_ent, int npe, const int *nodes, bool isEdge)
 {
   NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");

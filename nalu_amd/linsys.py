@@ -137,6 +137,13 @@ class GpuLinearSystem:
         self.n_owned, self.n_shared, self.n_ghost, self.n_cols = n_owned, n_shared, n_ghost, n
         self.gids, self.my_rank = gids.copy(), my_rank
 
+    def getDofStatus(self, node_lids):
+        """DofStatus of local nodes (src/TpetraLinearSystem.C:157-160, 2111-2157)."""
+        a = _np(np.atleast_1d(node_lids), np.int32)
+        st = np.zeros(len(a), np.int32)
+        L.check(self.lib.nalu_gpu_get_dof_status(self.h, len(a), a.ctypes.data, st.ctypes.data))
+        return st
+
     def buildNodeGraph(self, node_lids):
         a = _np(node_lids, np.int32)
         L.check(self.lib.nalu_gpu_build_node_graph(self.h, len(a), a.ctypes.data))

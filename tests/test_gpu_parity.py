@@ -817,3 +817,34 @@ def test_entry_parallel_assembly_kernel(G, torch, oracle, monkeypatch):
     g.zeroSystem()
     g.assemble_continuity_edges(t(xyz.T), t(dpdx.T), t(vel.T), t(p), t(rho), t(area.T), 0.1)
     _compare_system(g, ls, exact=True)
+
+
+def test_get_dof_status(G, oracle):
+    """unit_tests/UnitTestGetDofStatus.C:12-48: node 1 of generated:1x1x2 is an owned DOF; on
+    generated:10x10x10 split over ranks every globally shared node is DS_OwnedDOF on the rank
+    that owns it and DS_SharedNotOwnedDOF on the other rank that holds it; the remaining
+    non-owned nodes of a rank are ghosted."""
+    from nalu_amd._lib import DS_GhostedDOF, DS_OwnedDOF, DS_SharedNotOwnedDOF
+    g = G.GpuLinearSystem()
+    g.beginLinearSystemConstruction(12)
+    assert g.getDofStatus(0)[0] == DS_OwnedDOF  # global id 1
+    with pytest.raises(G.NaluGpuError):
+        g.getDofStatus(12)
+    for world in (2, 4):
+        holders = {}
+        for rank in range(world):
+            S = G.BoxSlab(11, 11, 11, rank, world)  # generated:10x10x10 = 11 nodes per side
+            g = G.GpuLinearSystem()
+            g.beginLinearSystemConstruction(S.n_owned, S.n_shared, S.n_ghost, S.gids, S.owners, rank)
+            st = g.getDofStatus(np.arange(S.n_local))
+            assert np.all(st[:S.n_owned] == DS_OwnedDOF)
+            assert np.all(st[S.n_owned:S.n_owned + S.n_shared] == DS_SharedNotOwnedDOF)
+            assert np.all(st[S.n_owned + S.n_shared:] == DS_GhostedDOF)
+            for lid in range(S.n_owned + S.n_shared):
+                holders.setdefault(int(S.gids[lid]), []).append((rank, int(st[lid]), int(S.owners[lid])))
+        shared = {gid: v for gid, v in holders.items() if len(v) > 1}
+        assert len(shared) == (world - 1) * 11 * 11  # the cut planes
+        for gid, v in shared.items():
+            assert sorted(s for _, s, _ in v) == [DS_OwnedDOF, DS_SharedNotOwnedDOF]
+            owner = [r for r, s, _ in v if s == DS_OwnedDOF][0]
+            assert all(o == owner for _, _, o in v)
