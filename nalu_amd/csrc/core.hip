@@ -141,6 +141,8 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   drain_timers(h);
+  for (nalu_gpu_scatter_plan *p : h->plans) release_plan(p);  // the structs stay the caller's
+  h->plans.clear();
   for (hipEvent_t e : h->eventPool) (void)hipEventDestroy(e);
   NG_FREE(h->dSliceOff); NG_FREE(h->dSliceWidth); NG_FREE(h->dCols); NG_FREE(h->dVals);
   NG_FREE(h->dTags); NG_FREE(h->dDiagPos); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);

@@ -76,6 +76,21 @@ struct EntBlock {
   std::vector<int> nodes;
 };
 
+// bulk sumInto plan (scatter.hip)
+struct nalu_gpu_scatter_plan {
+  nalu_gpu_linsys *h = nullptr;
+  int64_t nEnt = 0;
+  int nObj = 0;
+  std::vector<int> lids;        // host copy of the connectivity (colouring is lazy)
+  int *dRow = nullptr;          // [nEnt * nObj] owned row of local row i of entity e, or -1
+  short *dK = nullptr;          // [nEnt * nObj * nObj] entry index of column j in that row, or -1
+  long long *dIncPtr = nullptr; // [nOwned + 1] (entity, i) pairs per matrix row ...
+  int *dInc = nullptr;          // ... as e * nObj + i, ascending
+  int nColors = 0;
+  std::vector<int64_t> colorOff;
+  int *dColorPerm = nullptr;
+};
+
 struct nalu_gpu_linsys {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -168,6 +183,9 @@ struct nalu_gpu_linsys {
   nalu_gpu_comm comm{};
   bool hasComm = false;
 
+  // live bulk-sumInto plans (released with the system if the caller has not destroyed them)
+  std::vector<nalu_gpu_scatter_plan *> plans;
+
   // timers
   bool profiling = false;
   nalu_gpu::Timer timers[NALU_GPU_T_COUNT];
@@ -249,6 +267,7 @@ int halo_end(nalu_gpu_linsys *h, double *vec);
 // in a fixed order into dReduce[0..nslots) and (if a comm is set) all-reduces them.
 int finish_reduction(nalu_gpu_linsys *h, int nslots, int nblocks, const double *src = nullptr);
 int vec_grid(int64_t n);
+void release_plan(nalu_gpu_scatter_plan *p);
 int ensure_sgs_levels(nalu_gpu_linsys *h);
 int apply_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone);
 int ensure_mc_colors(nalu_gpu_linsys *h);

@@ -19,20 +19,6 @@
 
 using namespace nalu_gpu;
 
-struct nalu_gpu_scatter_plan {
-  nalu_gpu_linsys *h = nullptr;
-  int64_t nEnt = 0;
-  int nObj = 0;
-  std::vector<int> lids;        // host copy of the connectivity (colouring is lazy)
-  int *dRow = nullptr;          // [nEnt * nObj] owned row of local row i of entity e, or -1
-  short *dK = nullptr;          // [nEnt * nObj * nObj] entry index of column j in that row, or -1
-  long long *dIncPtr = nullptr; // [nOwned + 1] (entity, i) pairs per matrix row ...
-  int *dInc = nullptr;          // ... as e * nObj + i, ascending
-  int nColors = 0;
-  std::vector<int64_t> colorOff;
-  int *dColorPerm = nullptr;
-};
-
 namespace {
 
 template <typename F>
@@ -222,7 +208,8 @@ extern "C" int nalu_gpu_scatter_plan_create(nalu_gpu_linsys *h, int64_t n_ent, i
   do {                                                                                         \
     hipError_t e_ = (call);                                                                    \
     if (e_ != hipSuccess) {                                                                    \
-      nalu_gpu_scatter_plan_destroy(p);                                                        \
+      release_plan(p);                                                                         \
+      delete p;                                                                                \
       return set_error(NALU_GPU_EHIP, "%s failed: %s", #call, hipGetErrorString(e_));          \
     }                                                                                          \
   } while (0)
@@ -235,20 +222,32 @@ extern "C" int nalu_gpu_scatter_plan_create(nalu_gpu_linsys *h, int64_t n_ent, i
   NG_PLAN_HIP(hipMemcpy(p->dIncPtr, incPtr.data(), sizeof(long long) * incPtr.size(), hipMemcpyHostToDevice));
   NG_PLAN_HIP(hipMemcpy(p->dInc, inc.data(), sizeof(int) * inc.size(), hipMemcpyHostToDevice));
 #undef NG_PLAN_HIP
+  h->plans.push_back(p);
   *out = p;
   return NALU_GPU_OK;
 }
 
-extern "C" int nalu_gpu_scatter_plan_destroy(nalu_gpu_scatter_plan *p)
+// device memory of a plan; also called by nalu_gpu_destroy for plans that outlive their system
+void nalu_gpu::release_plan(nalu_gpu_scatter_plan *p)
 {
-  if (!p) return NALU_GPU_OK;
-  (void)hipSetDevice(p->h->device);
-  (void)hipStreamSynchronize(p->h->stream);
   if (p->dRow) (void)hipFree(p->dRow);
   if (p->dK) (void)hipFree(p->dK);
   if (p->dIncPtr) (void)hipFree(p->dIncPtr);
   if (p->dInc) (void)hipFree(p->dInc);
   if (p->dColorPerm) (void)hipFree(p->dColorPerm);
+  p->dRow = nullptr; p->dK = nullptr; p->dIncPtr = nullptr; p->dInc = nullptr; p->dColorPerm = nullptr;
+  p->h = nullptr;
+}
+
+extern "C" int nalu_gpu_scatter_plan_destroy(nalu_gpu_scatter_plan *p)
+{
+  if (!p) return NALU_GPU_OK;
+  if (nalu_gpu_linsys *h = p->h) {  // null: the system was destroyed first and released the plan
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    h->plans.erase(std::remove(h->plans.begin(), h->plans.end(), p), h->plans.end());
+    release_plan(p);
+  }
   delete p;
   return NALU_GPU_OK;
 }
@@ -256,6 +255,7 @@ extern "C" int nalu_gpu_scatter_plan_destroy(nalu_gpu_scatter_plan *p)
 extern "C" int nalu_gpu_scatter_plan_colors(nalu_gpu_scatter_plan *p, int *n_colors)
 {
   NG_REQUIRE(p && n_colors, NALU_GPU_EINVAL, "null plan / out");
+  NG_REQUIRE(p->h, NALU_GPU_ESTATE, "the plan's linear system was destroyed");
   NG_HIP(hipSetDevice(p->h->device));
   NG_TRY(ensure_plan_colors(p));
   *n_colors = p->nColors;

@@ -81,7 +81,8 @@ class ScatterPlan:
         return n.value
 
     def close(self):
-        if self.p and self.owner.h:
+        # safe in either order: a system that is destroyed first releases its plans' device memory
+        if self.p:
             self.owner.lib.nalu_gpu_scatter_plan_destroy(self.p)
         self.p = C.c_void_p()
 

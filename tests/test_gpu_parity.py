@@ -655,6 +655,11 @@ def test_bulk_sum_into_tpetra_gold(G, torch, oracle):
         g.loadComplete()
         np.testing.assert_allclose(dense(rp, ci, g.matrix_values(), 12), LHS_VALS, atol=1e-9, rtol=0)
     assert plan.n_colors() == 2  # the two hexes share a face
+    # destroying the system first releases the plan's device memory; the plan handle stays valid
+    # to destroy, and using it reports the state instead of touching freed memory
+    g.close()
+    with pytest.raises(G.NaluGpuError, match="destroyed"):
+        plan.n_colors()
     plan.close()
 
 
