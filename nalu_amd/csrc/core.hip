@@ -148,7 +148,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dTags); NG_FREE(h->dDiagPos); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
-  NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
+  NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   NG_FREE(h->dY); NG_FREE(h->dList); NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf);
   NG_FREE(h->dRecvBuf);
@@ -398,6 +398,53 @@ __global__ __launch_bounds__(SELL_C) void k_tag_offsets(int nRows, const long lo
   if ((r & 63) == 0) exMaskT[(size_t)slice * 4 + (r >> 6)] = m;
 }
 
+// Entry order of the assembly row kernel, one thread per slice.  Entries whose neighbour lies
+// outside the slice for (nearly) every row -- column offset of at least half a slice -- are
+// visited first, in ascending k, then the others: on a lattice the gathers z-, y-, y+, z+ go out
+// back to back and x-, x+ (served from LDS) follow, so that all users of a nodal line touch it
+// within a few microseconds of each other and it is still in L2.  The
+// shares are added in CSR order all the same: an entry visited before a smaller one is flagged
+// "early" and the kernel stashes its shares (two slots; orders that would need more fall back
+// to the identity, as do slices wider than 8 entries).
+__global__ void k_slice_order(int nSlices, const long long *sliceOff, const int *sliceWidth,
+                              const int *kOff, const unsigned *tBase, const unsigned *tMul,
+                              unsigned *ordWord, int enabled)
+{
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nSlices) return;
+  const int w = sliceWidth[s];
+  const long long o = sliceOff[s] / SELL_C;
+  unsigned word = ORD_IDENTITY;
+  if (enabled && w <= 8) {
+    int ord[8], n = 0;
+    bool ext[8];
+    for (int k = 0; k < w; ++k) {
+      const bool edge = tMul[o + k] != 0 || tBase[o + k] < TAG_OTHER;
+      const int d = kOff[o + k];
+      ext[k] = edge && (d >= SELL_C / 2 || d <= -SELL_C / 2);
+    }
+    for (int k = 0; k < w; ++k)
+      if (ext[k]) ord[n++] = k;
+    for (int k = 0; k < w; ++k)
+      if (!ext[k]) ord[n++] = k;
+    for (int k = w; k < 8; ++k) ord[n++] = k;
+    unsigned early = 0;
+    int nEarly = 0;
+    for (int i = 0; i < 8; ++i)
+      for (int j = i + 1; j < 8; ++j)
+        if (ord[j] < ord[i]) {
+          early |= 1u << i;
+          ++nEarly;
+          break;
+        }
+    if (nEarly <= 2) {
+      word = early << 24;
+      for (int i = 0; i < 8; ++i) word |= (unsigned)ord[i] << (3 * i);
+    }
+  }
+  ordWord[s] = word;
+}
+
 __global__ __launch_bounds__(SELL_C) void k_find_diag(int nRows, const long long *sliceOff,
                                                        const int *sliceWidth, const unsigned *tags,
                                                        long long *diagPos)
@@ -606,6 +653,15 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
     if (h->nSlices > 0)
       k_tag_offsets<<<h->nSlices, SELL_C, 0, h->stream>>>(nO, h->dSliceOff, h->dSliceWidth, h->dTags,
                                                           h->dTBase, h->dTMul, h->dExMaskT, on);
+    NG_HIP(hipGetLastError());
+  }
+  {
+    NG_HIP(hipMalloc(&h->dOrdWord, sizeof(unsigned) * (size_t)std::max(h->nSlices, 1)));
+    const int on = 1;
+    if (h->nSlices > 0)
+      k_slice_order<<<(h->nSlices + 255) / 256, 256, 0, h->stream>>>(h->nSlices, h->dSliceOff, h->dSliceWidth,
+                                                                      h->dKOff, h->dTBase, h->dTMul,
+                                                                      h->dOrdWord, on);
     NG_HIP(hipGetLastError());
   }
   NG_HIP(hipMalloc(&h->dDiagPos, sizeof(long long) * (size_t)std::max(nO, 1)));

@@ -27,6 +27,7 @@ constexpr unsigned TAG_PAD = 0xFFFFFFFFu;   // padding
 constexpr unsigned TAG_DIAG = 0xFFFFFFFEu;  // the diagonal entry
 constexpr unsigned TAG_OTHER = 0xFFFFFFFDu; // graph entry that no edge maps to
 constexpr unsigned TAG_MAX_EDGE = 0x7FFFFFF0u;
+constexpr unsigned ORD_IDENTITY = 0xFAC688u;  // entries 0..7 in order, none early
 
 struct SellView {
   const long long *sliceOff;
@@ -43,6 +44,10 @@ struct SellView {
   // numbered along the rows) unless the row is flagged in exMaskT
   const unsigned *tBase, *tMul;
   const unsigned long long *exMaskT;
+  // per-slice entry order of the assembly row kernel (finalize, k_slice_order): entry visited at
+  // position i < 8 is (ordWord >> 3 i) & 7, bit 24 + i says that a smaller entry follows later
+  // ("early": its diagonal / rhs shares wait in a stash so that they are added in CSR order)
+  const unsigned *ordWord;
   int nSlices;
   int nRows;
 };
@@ -124,6 +129,7 @@ struct nalu_gpu_linsys {
   int *dKOff = nullptr;
   unsigned long long *dExMask = nullptr, *dExMaskT = nullptr;
   unsigned *dTBase = nullptr, *dTMul = nullptr;
+  unsigned *dOrdWord = nullptr;  // nSlices
 
   // edges
   int *dEdgeL = nullptr, *dEdgeR = nullptr;
@@ -229,6 +235,7 @@ inline SellView sell_view(const nalu_gpu_linsys *h)
   v.tBase = h->dTBase;
   v.tMul = h->dTMul;
   v.exMaskT = h->dExMaskT;
+  v.ordWord = h->dOrdWord;
   v.nSlices = h->nSlices;
   v.nRows = h->nOwned;
   return v;

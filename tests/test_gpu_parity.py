@@ -759,13 +759,16 @@ def test_bulk_sum_into_edges_equals_fused_kernel(G, torch, oracle):
     _compare_system(g, ls, exact=True)
 
 
-def test_entry_parallel_assembly_kernel(G, torch, oracle, monkeypatch):
-    """NG_ASM_ENTRIES=1: the persistent entry-parallel variant of the row gather (one wave per
-    matrix entry of 64 rows, ordered sum of the diagonal / rhs shares through LDS) gives the
-    oracle's matrix and rhs bit for bit, like the row kernel: continuity and scalar operators,
-    a perturbed box, a ragged sliver, the 27-point element graph (slices wider than 8 entries)
-    and an unstructured graph (rows of ~20 entries, flagged slices)."""
-    monkeypatch.setenv("NG_ASM_ENTRIES", "1")
+@pytest.mark.parametrize("variant", ["NG_ASM_ENTRIES", "NG_ASM_ORDER"])
+def test_alternative_assembly_kernels(G, torch, oracle, monkeypatch, variant):
+    """The two opt-in variants of the row gather give the oracle's matrix and rhs bit for bit,
+    like the default row kernel.  NG_ASM_ENTRIES=1: persistent entry-parallel kernel (one wave per
+    matrix entry of 64 rows, ordered sum of the diagonal / rhs shares through LDS).
+    NG_ASM_ORDER=1: entries visited out-of-slice neighbours first, shares still added in CSR
+    order through a stash.  Cases: continuity and scalar operators, a perturbed box, a ragged
+    sliver, a box whose lines straddle slices, the 27-point element graph (slices wider than 8
+    entries) and an unstructured graph (rows of ~20 entries, flagged slices)."""
+    monkeypatch.setenv(variant, "1")
     for dims, perturb in (((20, 20, 20), 0.125), ((2, 3, 70), 0.0), ((67, 5, 9), 0.125)):
         c = Case(oracle, 0, perturb, dims=dims)
         d = c.dev(torch)
