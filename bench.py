@@ -57,8 +57,11 @@ def build_rank(n, rank, nranks, device, strong=False):
     g = nalu_amd.GpuLinearSystem(1, torch.device(device).index or 0,
                                  torch.cuda.current_stream().cuda_stream)
     g.beginLinearSystemConstruction(S.n_owned, S.n_shared, S.n_ghost, S.gids, S.owners, rank)
+    t0 = time.perf_counter()
     g.buildEdgeToNodeGraph(S.edge_nodes)
     g.finalizeLinearSystem()
+    g.synchronize()
+    g.graph_setup_s = time.perf_counter() - t0  # the reference's `init` timer (not in the step)
     comm = None
     if nranks > 1:
         from nalu_amd.comm import TorchComm
@@ -288,6 +291,7 @@ def main():
                            "scalar transport edge assembly (upwind, van Leer limiter) + mass term + "
                            "GMRES(50)/Jacobi (tol 1e-5, max_it 50)"),
                        "nodes": Ng, "edges": Eg, "scatter": a.mode, "solver_iterations": iters,
+                       "graph_setup_s": round(getattr(g, "graph_setup_s", 0.0), 3),
                        "parallelism": f"z-slabs x{world}"},
             "roofline": {"kernel": "k_spmv<DOT> (SELL-256 SpMV fused with p.Ap)" if a.workload == "continuity"
                          else "k_spmv<DINV> (SELL-256 SpMV with the right-preconditioner column scaling)",
