@@ -42,6 +42,13 @@ struct ContOp {
     E.av[0] = P.f.edge_area.x[e]; E.av[1] = P.f.edge_area.y[e]; E.av[2] = P.f.edge_area.z[e];
     return E;
   }
+  // the edge seen from its R node: area vector reversed
+  __device__ static __forceinline__ Edge mirrored(const Edge &E, bool flip)
+  {
+    Edge M;
+    M.av[0] = flip ? -E.av[0] : E.av[0]; M.av[1] = flip ? -E.av[1] : E.av[1]; M.av[2] = flip ? -E.av[2] : E.av[2];
+    return M;
+  }
   // src/AssembleContinuityEdgeSolverAlgorithm.C:163-203; returns tmdot
   __device__ static __forceinline__ double flux(const Params &P, const Edge &E, const Node &L,
                                                 const Node &R, double &lhsfac)
@@ -124,6 +131,14 @@ struct ScalOp {
     E.av[0] = P.f.edge_area.x[e]; E.av[1] = P.f.edge_area.y[e]; E.av[2] = P.f.edge_area.z[e];
     E.mdot = P.f.mass_flow_rate[e];
     return E;
+  }
+  // the edge seen from its R node: area vector and mass flow reversed
+  __device__ static __forceinline__ Edge mirrored(const Edge &E, bool flip)
+  {
+    Edge M;
+    M.av[0] = flip ? -E.av[0] : E.av[0]; M.av[1] = flip ? -E.av[1] : E.av[1]; M.av[2] = flip ? -E.av[2] : E.av[2];
+    M.mdot = flip ? -E.mdot : E.mdot;
+    return M;
   }
   // src/AssembleScalarEdgeSolverAlgorithm.C:199-309
   __device__ static __forceinline__ void edge(const Params &P, const Edge &E, const Node &L,
@@ -212,12 +227,6 @@ struct ScalOp {
   }
 };
 
-template <class Node>
-__device__ __forceinline__ Node select(bool c, const Node &a, const Node &b)
-{
-  return c ? a : b;
-}
-
 // --------------------------------------------------------------------------------------
 // Row-gather ("owner computes") assembly: one thread per matrix row walks the row's
 // entries, recomputes the flux of each incident edge and keeps only its own row's share.
@@ -305,16 +314,16 @@ __global__ __launch_bounds__(SELL_C, ORDERED ? Op::kOrderedWaves : 1) void k_ass
         }
         const bool isR = (tag >> 31) != 0;
         double lhs[4], rh[2];
-        Op::edge(P, E, select(isR, nb, own), select(isR, own, nb), lhs, rh);
-        const double offd = isR ? lhs[2] : lhs[1];
+        Op::edge(P, Op::mirrored(E, isR), own, nb, lhs, rh);  // (the row's node plays L, see below)
+        const double offd = lhs[1];
         if (SET) A.vals[pos] = offd;
         else A.vals[pos] += offd;
         if (early) {
-          st[2 * nSt * SELL_C] = isR ? lhs[3] : lhs[0];
-          st[(2 * nSt + 1) * SELL_C] = isR ? rh[1] : rh[0];
+          st[2 * nSt * SELL_C] = lhs[0];
+          st[(2 * nSt + 1) * SELL_C] = rh[0];
         } else {
-          diag += isR ? lhs[3] : lhs[0];
-          b += isR ? rh[1] : rh[0];
+          diag += lhs[0];
+          b += rh[0];
         }
       } else if (tag == TAG_DIAG) {
         diagPos = pos;
@@ -353,10 +362,14 @@ __global__ __launch_bounds__(SELL_C, ORDERED ? Op::kOrderedWaves : 1) void k_ass
         nb = Op::load(P, c);
       }
       double lhs[4], rh[2];
-      Op::edge(P, Op::load_edge(P, e), select(isR, nb, own), select(isR, own, nb), lhs, rh);
-      const double offd = isR ? lhs[2] : lhs[1];
-      diag += isR ? lhs[3] : lhs[0];
-      b += isR ? rh[1] : rh[0];
+      // Both edge kernels are exactly invariant under swapping L and R together with the sign of
+      // the area vector (and of the mass flow): every term changes sign or stays, bit for bit
+      // (the oracle's mirror test).  So the row's node always plays L, and
+      // its shares are lhs[0], lhs[1], rhs[0] -- no per-field selects.
+      Op::edge(P, Op::mirrored(Op::load_edge(P, e), isR), own, nb, lhs, rh);
+      const double offd = lhs[1];
+      diag += lhs[0];
+      b += rh[0];
       if (SET) A.vals[pos] = offd;
       else A.vals[pos] += offd;
     }
@@ -470,12 +483,12 @@ __global__ __launch_bounds__(QROWS * NW) void k_assemble_entries(SellView A, typ
           }
           const bool isR = (tag >> 31) != 0;
           double lhs[4], rh[2];
-          Op::edge(P, E, select(isR, nb, own), select(isR, own, nb), lhs, rh);
-          const double offd = isR ? lhs[2] : lhs[1];
+          Op::edge(P, Op::mirrored(E, isR), own, nb, lhs, rh);  // (the row's node plays L)
+          const double offd = lhs[1];
           if (SET) A.vals[pos] = offd;
           else A.vals[pos] += offd;
-          ldsD[buf][k * QROWS + lane] = isR ? lhs[3] : lhs[0];
-          ldsB[buf][k * QROWS + lane] = isR ? rh[1] : rh[0];
+          ldsD[buf][k * QROWS + lane] = lhs[0];
+          ldsB[buf][k * QROWS + lane] = rh[0];
           kind = 1;
         } else if (tag == TAG_DIAG) {
           kind = 2;
