@@ -13,6 +13,7 @@
 //           per colour, plain adds: deterministic, order of additions = colour order.
 //   ATOMIC  one thread per (entity, local row), fp64 atomics: not bit-reproducible.
 #include <algorithm>
+#include <atomic>
 #include <thread>
 
 #include "internal.hpp"
@@ -156,7 +157,7 @@ extern "C" int nalu_gpu_scatter_plan_create(nalu_gpu_linsys *h, int64_t n_ent, i
   // rows beyond the owned ones are assembled by their owner (see nalu_gpu_sum_into)
   std::vector<int> rowOf((size_t)std::max<int64_t>(tot, 1));
   std::vector<short> kIdx((size_t)std::max<int64_t>(tot * n_obj, 1));
-  bool tooWide = false;
+  std::atomic<bool> tooWide(false);
   parallel_for(n_ent, [&](int64_t e0, int64_t e1) {
     for (int64_t e = e0; e < e1; ++e) {
       const int *en = &p->lids[e * n_obj];
