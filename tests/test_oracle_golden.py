@@ -353,3 +353,33 @@ def test_multicolour_sgs(oracle):
         z = np.linalg.solve(D + Up, D @ np.linalg.solve(D + Lp, b))
         alpha = (b @ z) / (z @ (A @ z))
         np.testing.assert_allclose(out["x"], alpha * z, rtol=1e-12, atol=1e-14)
+
+
+def test_sum_into_row_single_pass_scan(oracle):
+    """sum_into_row (src/TpetraLinearSystem.C:1363-1383) passes once through the CSR row with the
+    columns of the call in ascending order: a column that is not in the row runs the scan to the
+    row's end, so that column AND every larger one are dropped (the offset never moves back).
+    The oracle restates exactly that; the GPU host and bulk paths are compared with it in
+    tests/test_gpu_parity.py::test_bulk_sum_into_edges_equals_fused_kernel."""
+    # path graph 0-1-2-3: rows {0,1}, {0,1,2}, {1,2,3}, {2,3}
+    ls = oracle.LinSys(1, 4)
+    ls.add_connections(np.array([[0, 1], [1, 2], [2, 3]], np.int32))
+    ls.finalize()
+    ls.zero()
+    # entity {0, 3}: row 0 has column 0 but not 3 -> (0,0) lands; row 3: column 0 is missing, the
+    # scan ends, column 3 (the diagonal!) is dropped as well
+    ls.sum_into([0, 3], [1.0, 1.0], [[1.0, 7.0], [9.0, 2.0]])
+    rp, ci, v = ls.owned_csr()
+    A = np.zeros((4, 4))
+    for r in range(4):
+        A[r, ci[rp[r]:rp[r + 1]]] = v[rp[r]:rp[r + 1]]
+    assert A[0, 0] == 1.0 and A[3, 3] == 0.0 and A.sum() == 1.0
+    assert ls.owned_rhs().tolist() == [1.0, 0.0, 0.0, 1.0]  # the rhs is added regardless
+    # entity {3, 1} (unsorted input): sorted columns (1, 3); row 3 = {2, 3}: column 1 missing ->
+    # nothing lands; row 1 = {0, 1, 2}: column 1 lands, column 3 is missing
+    ls.sum_into([3, 1], [0.0, 0.0], [[5.0, 6.0], [7.0, 8.0]])
+    rp, ci, v = ls.owned_csr()
+    B = np.zeros((4, 4))
+    for r in range(4):
+        B[r, ci[rp[r]:rp[r + 1]]] = v[rp[r]:rp[r + 1]]
+    assert B[1, 1] == 8.0 and B[3, 3] == 0.0 and B.sum() == 9.0
