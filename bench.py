@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=192, help="box size of the CPU baseline sample (0 = skip)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): n^3 nodes per GPU; strong: one n^3 box split over the GPUs")
+    ap.add_argument("--check-every", type=int, default=0,
+                    help="iterations between host polls of the device convergence flag (0 = library default 10; "
+                         "results do not depend on it)")
     ap.add_argument("--variants", action="store_true", help="also time the colored/atomic scatter variants")
     ap.add_argument("--workload", default="continuity", choices=["continuity", "scalar"],
                     help="continuity = the headline Poisson step (default); scalar = BASELINE config 4: "
@@ -169,7 +172,7 @@ def main():
     strong = a.scaling == "strong"
     S, F, g, comm = build_rank(n, rank, world, device, strong)
     cfg = nalu_amd.LinearSolverConfig(method="cg", preconditioner="jacobi", tolerance=1e-5,
-                                      max_iterations=50, kspace=50)
+                                      max_iterations=50, kspace=50, check_every=a.check_every)
     pin = rank == 0
     p0 = float(F["p"][0].item()) if pin else 0.0
     # the continuity equation system as the reference registers it: interior edge algorithm
