@@ -572,7 +572,7 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
     // as it stands, kept as the starting point for a pipelined version.
     // Grid = what fits the chip at once, a multiple of 8 so that a workgroup stays on its XCD's
     // share of the schedule.
-    const bool entries = getenv("NG_ASM_ENTRIES") && atoi(getenv("NG_ASM_ENTRIES")) != 0;
+    const bool entries = h->asmVariant == 1;
     const int nQ = h->nSlices * (SELL_C / QROWS);
     timer_begin(h, NALU_GPU_T_ASSEMBLE_EDGES);
     if (entries && h->maxSliceWidth <= 32) {
@@ -585,7 +585,7 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
       int grid = std::max(1, perCu) * std::max(1, cus);
       grid = std::min((grid + 7) / 8 * 8, (nQ + 7) / 8 * 8);
       kern<<<grid, QROWS * 8, 0, h->stream>>>(sell_view(h), P, h->dRhs);
-    } else if (getenv("NG_ASM_ORDER") && atoi(getenv("NG_ASM_ORDER")) != 0) {
+    } else if (h->asmVariant == 2) {
       // NG_ASM_ORDER=1: the slice's out-of-slice entries first (k_slice_order).  HBM traffic falls
       // from 7.3 to 4.7 GB per launch at 256^3, but the 18 extra registers cost a wave per SIMD
       // and the kernel then sits on the L2 -> L1 bandwidth: 1.48 against 1.25 ms.

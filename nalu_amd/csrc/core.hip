@@ -611,6 +611,9 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
 
   // slice schedule of the row kernels (tuning knob)
   if (const char *e = getenv("NG_XCD_RUN")) h->xcdRun = atoi(e);
+  // experimental variants of the row-gather assembly, read once here
+  if (const char *e = getenv("NG_ASM_ENTRIES")) h->asmVariant = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("NG_ASM_ORDER")) h->asmVariant = atoi(e) ? 2 : h->asmVariant;
 
   // edges: SoA copy on the device + per-entry edge tags
   if (h->nEdges > 0) {

@@ -126,6 +126,7 @@ struct nalu_gpu_linsys {
   unsigned *dTags = nullptr;
   long long *dDiagPos = nullptr;  // SELL position of each row's diagonal entry (-1: none)
   int xcdRun = 8;  // slices per XCD run of the row-kernel schedule (NG_XCD_RUN)
+  int asmVariant = 0;  // 0 row kernel (default), 1 entry-parallel (NG_ASM_ENTRIES), 2 ordered (NG_ASM_ORDER)
   int *dKOff = nullptr;
   unsigned long long *dExMask = nullptr, *dExMaskT = nullptr;
   unsigned *dTBase = nullptr, *dTMul = nullptr;
