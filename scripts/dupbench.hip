@@ -8,6 +8,7 @@
 //   5 own + line s+256 at once (the z neighbour)        6 the same one round trip later
 //   7 own + all four neighbour lines (s-1, s+1, s-256, s+256): the row kernel's gathers without
 //     its arithmetic -- 57.7 M lines through the L2 per launch
+//   8 own + eight 8-byte stores per row (the matrix values + rhs of the row kernel)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +24,7 @@ __device__ __forceinline__ int xcd_run(int b, int n, int G)
   return ((idx / G) * 8 + xcd) * G + idx % G;
 }
 
-__global__ __launch_bounds__(256) void k(Fields F, int nSlices, int mode, double *out)
+__global__ __launch_bounds__(256) void k(Fields F, int nSlices, int mode, double *out, double *big)
 {
   const int s = xcd_run(blockIdx.x, nSlices, 8);
   const long long n = (long long)nSlices * 256;
@@ -60,6 +61,11 @@ __global__ __launch_bounds__(256) void k(Fields F, int nSlices, int mode, double
   }
 #pragma unroll
   for (int i = 0; i < NF; ++i) acc += own[i];
+  if (mode == 8) {
+    const long long base = (long long)s * 256 * 8 + threadIdx.x;  // SELL-like: 8 entries x 256 rows
+#pragma unroll
+    for (int j = 0; j < 8; ++j) big[base + j * 256] = acc + j;
+  }
   if (acc == 1.2345e300) out[0] = acc;
 }
 
@@ -75,13 +81,14 @@ int main(int argc, char **argv)
     CK(hipMemset(p, 0, n * 8));
     F.f[i] = p;
   }
-  double *out;
+  double *out, *big;
   CK(hipMalloc(&out, 8));
+  CK(hipMalloc(&big, n * 8 * 8));
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipEventRecord(a));
-    k<<<nSlices, 256>>>(F, nSlices, mode, out);
+    k<<<nSlices, 256>>>(F, nSlices, mode, out, big);
     CK(hipEventRecord(b));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, a, b));
