@@ -9,6 +9,7 @@
 //   7 own + all four neighbour lines (s-1, s+1, s-256, s+256): the row kernel's gathers without
 //     its arithmetic -- 57.7 M lines through the L2 per launch
 //   8 own + eight 8-byte stores per row (the matrix values + rhs of the row kernel)
+//   9 the same with nontemporal stores
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -61,10 +62,15 @@ __global__ __launch_bounds__(256) void k(Fields F, int nSlices, int mode, double
   }
 #pragma unroll
   for (int i = 0; i < NF; ++i) acc += own[i];
-  if (mode == 8) {
+  if (mode == 8 || mode == 9) {
     const long long base = (long long)s * 256 * 8 + threadIdx.x;  // SELL-like: 8 entries x 256 rows
+    if (mode == 8) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) big[base + j * 256] = acc + j;
+      for (int j = 0; j < 8; ++j) big[base + j * 256] = acc + j;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) __builtin_nontemporal_store(acc + j, big + base + j * 256);
+    }
   }
   if (acc == 1.2345e300) out[0] = acc;
 }
