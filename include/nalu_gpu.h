@@ -97,6 +97,20 @@ int nalu_gpu_get_solution(nalu_gpu_linsys *h, double *x /* n_rows */);
 int nalu_gpu_set_matrix_values(nalu_gpu_linsys *h, const double *values /* nnz */);
 int nalu_gpu_set_rhs(nalu_gpu_linsys *h, const double *rhs /* n_rows */);
 
+/* Layout diagnostics (no reference counterpart): the device matrix is SELL-256; rows whose
+ * k-th column / edge id is `row + constant(slice, k)` take a fast path of the row kernels that
+ * computes them instead of loading them.  Tests use this to assert which path a mesh numbering
+ * exercises; bench.py reports it. */
+typedef struct {
+  int64_t n_slices, sell_slots;
+  int max_slice_width;
+  int64_t rows_computed_columns; /* owned rows whose column indices are computed (SpMV, assembly) */
+  int64_t rows_computed_tags;    /* owned rows whose edge ids are computed (row-gather assembly) */
+  int assembly_variant;          /* row-gather kernel variant in force (0 = default) */
+  int xcd_run;                   /* slices per XCD run of the row-kernel schedule */
+} nalu_gpu_layout_info;
+int nalu_gpu_get_layout_info(nalu_gpu_linsys *h, nalu_gpu_layout_info *info);
+
 /* ---- assembly ------------------------------------------------------------------------
  * zeroSystem (src/TpetraLinearSystem.C:1331-1348) */
 int nalu_gpu_zero_system(nalu_gpu_linsys *h);

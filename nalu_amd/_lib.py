@@ -32,7 +32,7 @@ SYMBOLS = [
     "nalu_gpu_field_axpby", "nalu_gpu_project_nodal_velocity", "nalu_gpu_compute_geometry_hex8", "nalu_gpu_set_halo_plan",
     "nalu_gpu_set_comm", "nalu_gpu_get_comm_buffers", "nalu_gpu_halo_exchange",
     "nalu_gpu_set_profiling", "nalu_gpu_get_timer", "nalu_gpu_reset_timers",
-    "nalu_gpu_synchronize",
+    "nalu_gpu_synchronize", "nalu_gpu_get_layout_info",
 ]
 
 
@@ -67,6 +67,12 @@ class SolveInfo(C.Structure):
     _fields_ = [("iters", C.c_int), ("final_resid", C.c_double), ("rhs_norm2", C.c_double),
                 ("precond_seconds", C.c_double), ("solve_seconds", C.c_double),
                 ("history_len", C.c_int)]
+
+
+class LayoutInfo(C.Structure):
+    _fields_ = [("n_slices", C.c_int64), ("sell_slots", C.c_int64), ("max_slice_width", C.c_int),
+                ("rows_computed_columns", C.c_int64), ("rows_computed_tags", C.c_int64),
+                ("assembly_variant", C.c_int), ("xcd_run", C.c_int)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
@@ -148,6 +154,7 @@ def load():
         "nalu_gpu_get_timer": [vp, ci, P(dbl), P(i64)],
         "nalu_gpu_reset_timers": [vp],
         "nalu_gpu_synchronize": [vp],
+        "nalu_gpu_get_layout_info": [vp, P(LayoutInfo)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

@@ -725,13 +725,6 @@ __global__ __launch_bounds__(256) void k_project_velocity(long long n, double pr
 
 }  // namespace
 
-#define NG_FINALIZED(h)                                         \
-  do {                                                          \
-    NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");              \
-    NG_REQUIRE((h)->state == 2, NALU_GPU_ESTATE,                \
-               "linear system is not finalized");               \
-    NG_HIP(hipSetDevice((h)->device));                          \
-  } while (0)
 
 extern "C" int nalu_gpu_assemble_continuity_edges(nalu_gpu_linsys *h,
                                                   const nalu_gpu_continuity_fields *f, double dt,
@@ -815,7 +808,7 @@ extern "C" int nalu_gpu_field_axpby(nalu_gpu_linsys *h, int64_t n, double alpha,
 {
   NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
   NG_REQUIRE(n >= 0 && (n == 0 || (x && y)), NALU_GPU_EINVAL, "field_axpby: bad arguments");
-  NG_HIP(hipSetDevice(h->device));
+  NG_DEVICE(h->device);
   if (n) k_axpby<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(n, alpha, x, beta, y);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
@@ -831,7 +824,7 @@ extern "C" int nalu_gpu_project_nodal_velocity(nalu_gpu_linsys *h, int64_t n, do
   NG_REQUIRE(n >= 0 && gamma1 != 0.0, NALU_GPU_EINVAL, "project_nodal_velocity: bad arguments");
   NG_REQUIRE(n == 0 || (vec3_ok(dpdx_new) && vec3_ok(dpdx_old) && density && vec3_ok(velocity)),
              NALU_GPU_EINVAL, "project_nodal_velocity: null device pointer");
-  NG_HIP(hipSetDevice(h->device));
+  NG_DEVICE(h->device);
   if (n)
     k_project_velocity<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(
         n, dt / gamma1, dpdx_new, dpdx_old, density, projected, velocity);

@@ -83,7 +83,7 @@ extern "C" int nalu_gpu_set_profiling(nalu_gpu_linsys *h, int enabled)
 extern "C" int nalu_gpu_synchronize(nalu_gpu_linsys *h)
 {
   NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
-  NG_HIP(hipSetDevice(h->device));
+  NG_DEVICE(h->device);
   NG_HIP(hipStreamSynchronize(h->stream));
   return NALU_GPU_OK;
 }
@@ -120,7 +120,7 @@ extern "C" int nalu_gpu_create(nalu_gpu_linsys **out, int device, int num_dof, v
   int ndev = 0;
   NG_HIP(hipGetDeviceCount(&ndev));
   NG_REQUIRE(device >= 0 && device < ndev, NALU_GPU_EINVAL, "device %d of %d", device, ndev);
-  NG_HIP(hipSetDevice(device));
+  NG_DEVICE(device);
   nalu_gpu_linsys *h = new nalu_gpu_linsys();
   h->device = device;
   h->numDof = num_dof;
@@ -138,7 +138,7 @@ extern "C" int nalu_gpu_create(nalu_gpu_linsys **out, int device, int num_dof, v
 extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
 {
   if (!h) return NALU_GPU_OK;
-  (void)hipSetDevice(h->device);
+  nalu_gpu::DeviceGuard ngGuard_(h->device);
   (void)hipStreamSynchronize(h->stream);
   drain_timers(h);
   for (nalu_gpu_scatter_plan *p : h->plans) release_plan(p);  // the structs stay the caller's
@@ -464,7 +464,7 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
 {
   NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
   NG_REQUIRE(h->state == 1, NALU_GPU_ESTATE, "finalize needs a system under construction");
-  NG_HIP(hipSetDevice(h->device));
+  NG_DEVICE(h->device);
   const int nO = h->nOwned;
 
   // addConnections + insert_graph_connections (src/TpetraLinearSystem.C:355-371,877-917):
@@ -641,6 +641,8 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
                                                       h->dTags, dErr);
     NG_HIP(hipGetLastError());
     int err[2] = {0, 0};
+    // the null-stream copy below does not wait for a non-blocking h->stream by itself
+    NG_HIP(hipStreamSynchronize(h->stream));
     NG_HIP(hipMemcpy(err, dErr, 2 * sizeof(int), hipMemcpyDeviceToHost));
     (void)hipFree(dErr);
     NG_REQUIRE(err[0] == 0, NALU_GPU_EINVAL, "internal: %d edge entries missing from the graph", err[0]);
@@ -728,13 +730,6 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
 }
 
 // --------------------------------------------------------------------------- views
-#define NG_FINALIZED(h)                                         \
-  do {                                                          \
-    NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");              \
-    NG_REQUIRE((h)->state == 2, NALU_GPU_ESTATE,                \
-               "linear system is not finalized");               \
-    NG_HIP(hipSetDevice((h)->device));                          \
-  } while (0)
 
 extern "C" int nalu_gpu_get_sizes(nalu_gpu_linsys *h, int64_t *n_rows, int64_t *n_cols, int64_t *nnz)
 {
@@ -750,6 +745,34 @@ extern "C" int nalu_gpu_get_graph(nalu_gpu_linsys *h, int64_t *row_ptr, int *col
   NG_FINALIZED(h);
   if (row_ptr) std::copy(h->rowPtr.begin(), h->rowPtr.end(), row_ptr);
   if (col_idx) std::copy(h->colIdx.begin(), h->colIdx.end(), col_idx);
+  return NALU_GPU_OK;
+}
+
+// rows of the matrix that take the computed-column / computed-tag fast paths of the row kernels
+extern "C" int nalu_gpu_get_layout_info(nalu_gpu_linsys *h, nalu_gpu_layout_info *info)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(info, NALU_GPU_EINVAL, "info is null");
+  const size_t nw = (size_t)std::max(h->nSlices, 1) * 4;
+  std::vector<unsigned long long> ex(nw, ~0ULL), exT(nw, ~0ULL);
+  NG_HIP(hipStreamSynchronize(h->stream));
+  if (h->nSlices > 0) {
+    NG_HIP(hipMemcpy(ex.data(), h->dExMask, sizeof(unsigned long long) * nw, hipMemcpyDeviceToHost));
+    NG_HIP(hipMemcpy(exT.data(), h->dExMaskT, sizeof(unsigned long long) * nw, hipMemcpyDeviceToHost));
+  }
+  int64_t cc = 0, ct = 0;
+  for (int r = 0; r < h->nOwned; ++r) {
+    const size_t wd = (size_t)(r / SELL_C) * 4 + ((r % SELL_C) >> 6);
+    cc += !((ex[wd] >> (r & 63)) & 1ULL);
+    ct += !((exT[wd] >> (r & 63)) & 1ULL);
+  }
+  info->n_slices = h->nSlices;
+  info->sell_slots = h->sellSize;
+  info->max_slice_width = h->maxSliceWidth;
+  info->rows_computed_columns = cc;
+  info->rows_computed_tags = ct;
+  info->assembly_variant = h->asmVariant;
+  info->xcd_run = h->xcdRun;
   return NALU_GPU_OK;
 }
 

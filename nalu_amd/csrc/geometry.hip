@@ -357,7 +357,7 @@ extern "C" int nalu_gpu_compute_geometry_hex8(nalu_gpu_linsys *h, int64_t n_elem
 {
   NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
   NG_REQUIRE(h->state == 2, NALU_GPU_ESTATE, "linear system is not finalized");
-  NG_HIP(hipSetDevice(h->device));
+  NG_DEVICE(h->device);
   NG_REQUIRE(n_elem >= 0 && n_elem < (1LL << 31) / 12, NALU_GPU_EINVAL,
              "element count %lld out of range", (long long)n_elem);
   NG_REQUIRE(coordinates_dev.x && coordinates_dev.y && coordinates_dev.z && dual_volume_dev,

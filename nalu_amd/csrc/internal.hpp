@@ -216,6 +216,37 @@ int set_error(int code, const char *fmt, ...);
     if (!(cond)) return nalu_gpu::set_error(code, __VA_ARGS__);       \
   } while (0)
 
+// Makes the handle's device current for the duration of an entry point and restores the
+// caller's device on the way out (a host that drives several GPUs, or a PyTorch process whose
+// current device differs, keeps its own current device).
+struct DeviceGuard {
+  int prev = -1, dev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int d) : dev(d)
+  {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) err = hipSetDevice(dev);
+  }
+  ~DeviceGuard()
+  {
+    if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+// (statements, not a do-while: the guard must live until the entry point returns)
+#define NG_DEVICE(devArg_)                                                                      \
+  nalu_gpu::DeviceGuard ngGuard_(devArg_);                                                     \
+  if (ngGuard_.err != hipSuccess)                                                           \
+    return nalu_gpu::set_error(NALU_GPU_EHIP, "hipSetDevice(%d) failed: %s", ngGuard_.dev, \
+                               hipGetErrorString(ngGuard_.err))
+
+#define NG_FINALIZED(h)                                                                     \
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");                                            \
+  NG_REQUIRE((h)->state == 2, NALU_GPU_ESTATE, "linear system is not finalized");           \
+  NG_DEVICE((h)->device)
+
 #define NG_TRY(call)            \
   do {                          \
     int rc_ = (call);           \

@@ -137,7 +137,7 @@ extern "C" int nalu_gpu_scatter_plan_create(nalu_gpu_linsys *h, int64_t n_ent, i
   NG_REQUIRE(n_ent >= 0 && n_obj >= 1 && n_obj <= 64 && (ent_lids || n_ent == 0), NALU_GPU_EINVAL,
              "scatter plan: 1..64 nodes per entity (got %d)", n_obj);
   NG_REQUIRE(n_ent * n_obj < 2147483647LL, NALU_GPU_EUNSUPPORTED, "scatter plan: too many entities");
-  NG_HIP(hipSetDevice(h->device));
+  NG_DEVICE(h->device);
   const int64_t tot = n_ent * n_obj;
   for (int64_t t = 0; t < tot; ++t)
     NG_REQUIRE(ent_lids[t] >= 0 && ent_lids[t] < h->nCols, NALU_GPU_EINVAL,
@@ -244,7 +244,7 @@ extern "C" int nalu_gpu_scatter_plan_destroy(nalu_gpu_scatter_plan *p)
 {
   if (!p) return NALU_GPU_OK;
   if (nalu_gpu_linsys *h = p->h) {  // null: the system was destroyed first and released the plan
-    (void)hipSetDevice(h->device);
+    nalu_gpu::DeviceGuard ngGuard_(h->device);
     (void)hipStreamSynchronize(h->stream);
     h->plans.erase(std::remove(h->plans.begin(), h->plans.end(), p), h->plans.end());
     release_plan(p);
@@ -257,7 +257,7 @@ extern "C" int nalu_gpu_scatter_plan_colors(nalu_gpu_scatter_plan *p, int *n_col
 {
   NG_REQUIRE(p && n_colors, NALU_GPU_EINVAL, "null plan / out");
   NG_REQUIRE(p->h, NALU_GPU_ESTATE, "the plan's linear system was destroyed");
-  NG_HIP(hipSetDevice(p->h->device));
+  NG_DEVICE(p->h->device);
   NG_TRY(ensure_plan_colors(p));
   *n_colors = p->nColors;
   return NALU_GPU_OK;
@@ -271,7 +271,7 @@ extern "C" int nalu_gpu_sum_into_batch(nalu_gpu_linsys *h, nalu_gpu_scatter_plan
   NG_REQUIRE(p->h == h && h->state == 2, NALU_GPU_ESTATE,
              "the plan belongs to another (or a not finalized) linear system");
   NG_REQUIRE(p->nEnt == 0 || (rhs_dev && lhs_dev), NALU_GPU_EINVAL, "null rhs / lhs");
-  NG_HIP(hipSetDevice(h->device));
+  NG_DEVICE(h->device);
   NG_TRY(materialize_zero(h));
   if (p->nEnt == 0 || h->nOwned == 0) return NALU_GPU_OK;
   const long long nThreads = (long long)p->nEnt * p->nObj;

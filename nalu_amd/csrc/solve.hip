@@ -1255,13 +1255,6 @@ int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int check
 
 }  // namespace
 
-#define NG_FINALIZED(h)                                         \
-  do {                                                          \
-    NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");              \
-    NG_REQUIRE((h)->state == 2, NALU_GPU_ESTATE,                \
-               "linear system is not finalized");               \
-    NG_HIP(hipSetDevice((h)->device));                          \
-  } while (0)
 
 extern "C" int nalu_gpu_spmv(nalu_gpu_linsys *h, const double *x_dev, double *y_dev)
 {

@@ -204,6 +204,12 @@ class GpuLinearSystem:
         L.check(self.lib.nalu_gpu_get_solution(self.h, x.ctypes.data))
         return x[:self.n_rows]
 
+    def layout_info(self):
+        """nalu_gpu_get_layout_info as a dict (which fast paths the mesh numbering gets)"""
+        li = L.LayoutInfo()
+        L.check(self.lib.nalu_gpu_get_layout_info(self.h, C.byref(li)))
+        return {k: getattr(li, k) for k, _ in li._fields_}
+
     # ---- MatrixMarket dumps (src/TpetraLinearSystem.C:1901-1924, 2002-2019) -----
     def writeToFile(self, base_filename, useOwned=True, eq_sys_name="", n_ranks=1,
                     n_global=None):
