@@ -379,7 +379,8 @@ public:
     linearSolveIterations_ = info.iters;
     nonLinearResidual_ = realm_.l2Scaling_ * info.rhs_norm2;
     linearResidual_ = info.final_resid;
-    timerPrecond_ += info.precond_seconds;
+    timerPrecond_ = info.precond_seconds;  // the last solve's (src/LinearSolver.C:211); the caller sums
+
     if (firstTimeStepSolve_) firstNonLinearResidual_ = nonLinearResidual_;
     scaledNonLinearResidual_ =
       nonLinearResidual_ / std::max(std::numeric_limits<double>::epsilon(), firstNonLinearResidual_);
@@ -706,7 +707,7 @@ public:
   EquationSystem(Realm &realm, const std::string &name, LinearSolverConfig *solver, unsigned numDof = 1)
     : realm_(realm), name_(name), linsys_(new GpuLinearSystem(realm, numDof, name, solver)),
       solverAlgDriver_(new SolverAlgorithmDriver()), timerAssemble_(0.0), timerLoadComplete_(0.0),
-      timerSolve_(0.0), timerInit_(0.0), numberLinearIterations_(0), deviceTimers_(false)
+      timerSolve_(0.0), timerInit_(0.0), timerPrecond_(0.0), numberLinearIterations_(0), deviceTimers_(false)
   {
   }
   ~EquationSystem()
@@ -745,6 +746,7 @@ public:
     error = linsys_->solve(deltaSolution);
     timeB = now();
     timerSolve_ += (timeB - timeA);
+    timerPrecond_ += linsys_->get_timer_precond();  // src/EquationSystem.C:292
     numberLinearIterations_ += linsys_->linearSolveIterations();  // update_iteration_statistics
 
     if (error > 0) std::cout << "Error in " << name_ << "::solve_and_update()  " << std::endl;
@@ -754,7 +756,7 @@ public:
   std::string name_;
   GpuLinearSystem *linsys_;
   SolverAlgorithmDriver *solverAlgDriver_;
-  double timerAssemble_, timerLoadComplete_, timerSolve_, timerInit_;
+  double timerAssemble_, timerLoadComplete_, timerSolve_, timerInit_, timerPrecond_;
   long long numberLinearIterations_;
   // the reference's timers bracket synchronous host code; GPU work is asynchronous, so the
   // buckets only mean device time when each reading synchronises the stream first

@@ -288,6 +288,10 @@ typedef struct {
   int (*exchange_end)(void *ctx, void *hip_stream);
 } nalu_gpu_comm;
 int nalu_gpu_set_comm(nalu_gpu_linsys *h, const nalu_gpu_comm *comm);
+/* A callback that fails (returns non-zero) may first leave a message here; the library appends
+ * it to the NALU_GPU_EHIP error it raises, so nalu_gpu_last_error() names the cause (the
+ * reference's MPI errors abort with their own text). */
+int nalu_gpu_set_callback_error(const char *message);
 int nalu_gpu_get_comm_buffers(nalu_gpu_linsys *h, double **send_buf_dev, int64_t *send_count,
                               double **recv_buf_dev, int64_t *recv_count,
                               double **reduce_buf_dev, int *reduce_capacity);

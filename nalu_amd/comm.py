@@ -7,6 +7,7 @@ reduce buffer on the device; this module only moves those bytes between ranks:
                      and stk::mesh::copy_owned_to_shared (src/LinearSystem.C:115)
   * all-reduce     = Tpetra dot / norm2 (src/LinearSolver.C:172, src/TpetraLinearSystem.C:1756)
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -59,6 +60,8 @@ class TorchComm:
         self.reduce = wrap_device(red, cap, device)
         self.pending = []
         self.errors = []
+        self._streams = {}
+        self.linsys_lib = linsys.lib
         # gloo (tests: several ranks on one GPU) has no device send/recv: stage through the host
         self.stage = dist.get_backend(group) == "gloo" and str(device).startswith("cuda")
         self._recv_host = None
@@ -83,44 +86,64 @@ class TorchComm:
                 ops.append(dist.P2POp(dist.irecv, recv[a:b], p, group=self.group))
         return ops
 
+    def _on(self, stream):
+        """Context that makes the library's stream (the callback's `stream` argument) torch's
+        current stream: torch.distributed orders its collectives against the CURRENT stream, and
+        the library has enqueued the pack / partial-sum kernels on ITS stream, which need not be
+        the one that is current when the callback runs (GpuLinearSystem(stream=...))."""
+        if not str(self.device).startswith("cuda"):
+            return contextlib.nullcontext()
+        key = int(stream or 0)
+        ts = self._streams.get(key)
+        if ts is None:
+            ts = (torch.cuda.ExternalStream(key, device=self.device) if key
+                  else torch.cuda.default_stream(self.device))  # hipStream_t 0 = the default stream
+            self._streams[key] = ts
+        return torch.cuda.stream(ts)
+
+    def _fail(self, e):
+        self.errors.append(repr(e))
+        self.linsys_lib.nalu_gpu_set_callback_error(repr(e).encode()[:900])
+        return 1
+
     # callbacks must never raise through ctypes: record and return non-zero
     def _allreduce(self, ctx, count, stream):
         try:
-            if self.stage:
-                t = self.reduce[:count].cpu()
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-                self.reduce[:count].copy_(t)
-            else:
-                v = self._views.get(count)
-                if v is None:
-                    v = self._views[count] = self.reduce[:count]
-                dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+            with self._on(stream):
+                if self.stage:
+                    t = self.reduce[:count].cpu()  # on the library's stream, then host-synchronous
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                    self.reduce[:count].copy_(t)
+                else:
+                    v = self._views.get(count)
+                    if v is None:
+                        v = self._views[count] = self.reduce[:count]
+                    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
             return 0
         except Exception as e:  # pragma: no cover
-            self.errors.append(repr(e))
-            return 1
+            return self._fail(e)
 
     def _exchange_begin(self, ctx, stream):
         try:
-            if self.stage:
-                send = self.send.cpu()
-                recv = self._recv_host = torch.empty(self.recv.shape, dtype=torch.float64)
-                self.pending = exchange_halo(send, recv, self.neighbors, self.so, self.ro, self.group)
-            else:
-                self.pending = dist.batch_isend_irecv(self._ops) if self._ops else []
+            with self._on(stream):
+                if self.stage:
+                    send = self.send.cpu()
+                    recv = self._recv_host = torch.empty(self.recv.shape, dtype=torch.float64)
+                    self.pending = exchange_halo(send, recv, self.neighbors, self.so, self.ro, self.group)
+                else:
+                    self.pending = dist.batch_isend_irecv(self._ops) if self._ops else []
             return 0
         except Exception as e:  # pragma: no cover
-            self.errors.append(repr(e))
-            return 1
+            return self._fail(e)
 
     def _exchange_end(self, ctx, stream):
         try:
-            for w in self.pending:
-                w.wait()
-            self.pending = []
-            if self.stage:
-                self.recv.copy_(self._recv_host)
+            with self._on(stream):
+                for w in self.pending:
+                    w.wait()  # nccl: makes the current (= the library's) stream wait for the data
+                self.pending = []
+                if self.stage:
+                    self.recv.copy_(self._recv_host)
             return 0
         except Exception as e:  # pragma: no cover
-            self.errors.append(repr(e))
-            return 1
+            return self._fail(e)

@@ -25,6 +25,22 @@ int nalu_gpu::set_error(int code, const char *fmt, ...)
 }
 
 extern "C" const char *nalu_gpu_last_error(void) { return g_err.c_str(); }
+
+// what a failing comm callback wants nalu_gpu_last_error() to say (callbacks cannot throw
+// through the C ABI); consumed by the next "callback failed" error of this thread
+static thread_local std::string g_cbErr;
+extern "C" int nalu_gpu_set_callback_error(const char *msg)
+{
+  g_cbErr = msg ? msg : "";
+  return NALU_GPU_OK;
+}
+const char *nalu_gpu::callback_error()
+{
+  static thread_local std::string last;
+  last = g_cbErr.empty() ? std::string("(the callback left no message)") : g_cbErr;
+  g_cbErr.clear();
+  return last.c_str();
+}
 extern "C" int nalu_gpu_version(void) { return 100; }
 
 // ------------------------------------------------------------------------- timers
@@ -1170,7 +1186,7 @@ int nalu_gpu::halo_begin(nalu_gpu_linsys *h, const double *vec)
                                                                           vec, h->dSendBuf);
   NG_HIP(hipGetLastError());
   NG_REQUIRE(h->comm.exchange_begin(h->comm.ctx, h->stream) == 0, NALU_GPU_EHIP,
-             "exchange_begin callback failed");
+             "exchange_begin callback failed: %s", callback_error());
   return NALU_GPU_OK;
 }
 
@@ -1178,7 +1194,7 @@ int nalu_gpu::halo_end(nalu_gpu_linsys *h, double *vec)
 {
   if (h->nCols == h->nOwned) return NALU_GPU_OK;
   NG_REQUIRE(h->comm.exchange_end(h->comm.ctx, h->stream) == 0, NALU_GPU_EHIP,
-             "exchange_end callback failed");
+             "exchange_end callback failed: %s", callback_error());
   NG_HIP(hipMemcpyAsync(vec + h->nOwned, h->dRecvBuf, sizeof(double) * (size_t)h->recvCount,
                         hipMemcpyDeviceToDevice, h->stream));
   return NALU_GPU_OK;

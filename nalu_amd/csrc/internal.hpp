@@ -202,6 +202,7 @@ struct nalu_gpu_linsys {
 namespace nalu_gpu {
 
 int set_error(int code, const char *fmt, ...);
+const char *callback_error();
 
 #define NG_HIP(call)                                                                   \
   do {                                                                                 \

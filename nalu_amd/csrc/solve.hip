@@ -155,7 +155,7 @@ int allreduce(nalu_gpu_linsys *h, int count)
 {
   if (!h->hasComm) return NALU_GPU_OK;
   NG_REQUIRE(h->comm.allreduce_sum(h->comm.ctx, count, h->stream) == 0, NALU_GPU_EHIP,
-             "allreduce_sum callback failed");
+             "allreduce_sum callback failed: %s", callback_error());
   return NALU_GPU_OK;
 }
 

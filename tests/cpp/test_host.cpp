@@ -562,7 +562,13 @@ static void test_write_matrix_files(const std::string &dir)
     new FixPressureAtNodeAlgorithm(*eqsys.linsys_, true, 0, 0.0, box.p[0]);
   eqsys.initialize();
   eqsys.assemble_and_solve(dp.p);
+  const double precond1 = eqsys.linsys_->get_timer_precond();
   eqsys.assemble_and_solve(dp.p);  // writeCounter_ advances: -O-0 and -O-1
+  // the linear system holds the LAST solve's preconditioner time (src/LinearSolver.C:211); the
+  // equation system is what sums it (src/EquationSystem.C:292)
+  const double precond2 = eqsys.linsys_->get_timer_precond();
+  EXPECT_TRUE(precond1 > 0.0 && precond2 > 0.0);
+  EXPECT_NEAR(eqsys.timerPrecond_, precond1 + precond2, 1e-12);
   for (int c = 0; c < 2; ++c) {
     std::ifstream mm(base + "-O-" + std::to_string(c) + ".mm.1");
     EXPECT_TRUE(mm.good());

@@ -79,7 +79,13 @@ def gpu_test(rank, world, method):
     assert np.array_equal(key[ge], lk)
     dev = "cuda:0"
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
-    g = nalu_amd.GpuLinearSystem(1, 0, torch.cuda.current_stream().cuda_stream)
+    # NALU_TEST_SIDE_STREAM=1: the system lives on a non-default stream and every library call is
+    # made with torch's DEFAULT stream current -- the comm callbacks must order their collectives
+    # against the library's stream, not against the current one (nalu_amd/comm.py)
+    side = torch.cuda.Stream() if os.environ.get("NALU_TEST_SIDE_STREAM") == "1" else None
+    stream = side.cuda_stream if side is not None else torch.cuda.current_stream().cuda_stream
+    assert side is None or stream != torch.cuda.current_stream().cuda_stream
+    g = nalu_amd.GpuLinearSystem(1, 0, stream)
     g.beginLinearSystemConstruction(S.n_owned, S.n_shared, S.n_ghost, S.gids, S.owners, rank)
     g.buildEdgeToNodeGraph(S.edge_nodes)
     g.finalizeLinearSystem()
@@ -89,23 +95,30 @@ def gpu_test(rank, world, method):
     def nodal(a):
         v = t(a[gi])
         v[S.n_owned:] = 0.0
+        torch.cuda.synchronize()  # torch wrote v on its own stream
         g.halo_exchange(v)
+        g.synchronize()
         return v
     coords = torch.stack([nodal(c.m.xyz[:, d]) for d in range(3)])
     area = t(c.area[ge].T)
+    torch.cuda.synchronize()
     g.zeroSystem()
     if method == "cg":
         dq = torch.stack([nodal(c.dqdx[:, d]) for d in range(3)])
         vel = torch.stack([nodal(c.vel[:, d]) for d in range(3)])
         q, rho, gam, vol = nodal(c.q), nodal(c.rho), nodal(c.gamma), nodal(c.vol)
-        g.assemble_scalar_edges(coords, dq, vel, q, rho, gam, area, t(c.mdot[ge]))
-        g.assemble_scalar_mass_be(0.9 * q, q, rho, rho, vol, c.dt)
+        mdot, q9 = t(c.mdot[ge]), 0.9 * q
+        torch.cuda.synchronize()
+        g.assemble_scalar_edges(coords, dq, vel, q, rho, gam, area, mdot)
+        g.assemble_scalar_mass_be(q9, q, rho, rho, vol, c.dt)
         ls = c.oracle_scalar()
         ls.assemble_scalar_mass_be(0.9 * c.q, c.q, c.rho, c.rho, c.vol, c.dt)
     else:
         dp = torch.stack([nodal(c.dpdx[:, d]) for d in range(3)])
         vel = torch.stack([nodal(c.vel[:, d]) for d in range(3)])
-        g.assemble_continuity_edges(coords, dp, vel, nodal(c.p), nodal(c.rho), area, c.dt)
+        pn, rn = nodal(c.p), nodal(c.rho)
+        torch.cuda.synchronize()
+        g.assemble_continuity_edges(coords, dp, vel, pn, rn, area, c.dt)
         ls = c.oracle_continuity()
         ls.reset_rows([0])
         ls.sum_into([0], [0.0 - c.p[0]], [1.0])
@@ -141,6 +154,7 @@ def gpu_test(rank, world, method):
     assert np.abs(g.history - ref["history"]).max() <= 1e-10
     ref = ls.solve(method, "jacobi", **kw)
     x = torch.zeros(S.n_local, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
     g.solve(nalu_amd.LinearSolverConfig(method=method, preconditioner="jacobi", **kw), x)
     assert not comm.errors, comm.errors
     assert g.linearSolveIterations == ref["iters"], (g.linearSolveIterations, ref["iters"])

@@ -8,8 +8,9 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _launch(nproc, *args, timeout=300, backend="gloo"):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", NALU_TEST_BACKEND=backend)
+def _launch(nproc, *args, timeout=300, backend="gloo", side_stream=False):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", NALU_TEST_BACKEND=backend,
+               NALU_TEST_SIDE_STREAM="1" if side_stream else "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 500),
            os.path.join(HERE, "dist_worker.py"), *args]
@@ -36,6 +37,15 @@ def test_comm_callbacks_over_rccl_world_1(method):
     test box only world size 1 fits: it still drives every reduction of the solver through
     dist.all_reduce on the library's wrapped device buffer (no host staging)."""
     _launch(1, "gpu", method, backend="nccl")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,backend", [(1, "nccl"), (2, "gloo")])
+def test_comm_on_a_non_default_stream(nproc, backend):
+    """GpuLinearSystem(stream=side stream) with torch's default stream current during the solve:
+    the TorchComm callbacks switch to the library's stream, so halos and dot products are ordered
+    after the kernels that produce them (same results as on the default stream)."""
+    _launch(nproc, "gpu", "cg", backend=backend, side_stream=True)
 
 
 @pytest.mark.gpu
