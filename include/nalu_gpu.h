@@ -230,6 +230,19 @@ int nalu_gpu_dot(nalu_gpu_linsys *h, const double *a_dev, const double *b_dev, i
 int nalu_gpu_axpy(nalu_gpu_linsys *h, double alpha, const double *x_dev, double *y_dev, int64_t n);
 int nalu_gpu_norm2(nalu_gpu_linsys *h, const double *a_dev, int64_t n, double *out);
 
+/* The ONE entry point that allocates nothing.  It has no counterpart in the reference: it is for
+ * callers that cannot call hipMalloc -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  Same result, bit for bit, as nalu_gpu_dot on one rank (same
+ * kernels, grid and summation order), but it needs no handle: the per-workgroup partial sums
+ * live in a static device array of 16,384 doubles (128 KiB, held by every GPU the library runs
+ * on until the process ends) and the result is written to out_dev (device memory, no host
+ * synchronisation).  n above NALU_GPU_DOT_STATIC_MAX_N is rejected with NALU_GPU_EINVAL.  No
+ * all-reduce over ranks.  Calls that overlap on one GPU (different streams or threads) share
+ * the array and race: serialise them. */
+#define NALU_GPU_DOT_STATIC_MAX_N (INT64_C(1) << 32)
+int nalu_gpu_dot_static(int device, void *hip_stream, const double *a_dev, const double *b_dev,
+                        int64_t n, double *out_dev);
+
 /* ---- adjacent edge algorithms ---------------------------------
  * ComputeMdotEdgeAlgorithm::execute (src/ComputeMdotEdgeAlgorithm.C:67-174) */
 int nalu_gpu_compute_mdot_edges(nalu_gpu_linsys *h, const nalu_gpu_continuity_fields *f_dev,

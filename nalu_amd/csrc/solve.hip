@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <mutex>
 
 #include "internal.hpp"
 
@@ -1275,6 +1276,52 @@ extern "C" int nalu_gpu_dot(nalu_gpu_linsys *h, const double *a, const double *b
   NG_HIP(hipMemcpyAsync(h->hPinned, h->dReduce, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   NG_HIP(hipStreamSynchronize(h->stream));
   *out = *(double *)h->hPinned;
+  return NALU_GPU_OK;
+}
+
+// ---- the one entry point that allocates nothing (include/nalu_gpu.h: nalu_gpu_dot_static) ----
+// Scratch of the dot product's first stage (one partial sum per workgroup of k_dot) in a
+// file-scope device array instead of the handle's hipMalloc'ed workspace.  `dotScratch` is a
+// host-side stand-in here, NOT a device address: every GPU holds its own copy at its own
+// address, looked up once per device with hipGetSymbolAddress and kept in g_dotScratchPtr;
+// host code passes that pointer, never the array's name, to kernels.
+static __device__ __align__(256) double dotScratch[MAX_BLOCKS];
+namespace {
+constexpr int DOT_STATIC_MAX_DEVICES = 64;
+double *g_dotScratchPtr[DOT_STATIC_MAX_DEVICES] = {};
+std::mutex g_dotScratchMutex;
+}  // namespace
+
+extern "C" int nalu_gpu_dot_static(int device, void *hip_stream, const double *a_dev, const double *b_dev,
+                                   int64_t n, double *out_dev)
+{
+  NG_REQUIRE(n >= 0 && n <= NALU_GPU_DOT_STATIC_MAX_N, NALU_GPU_EINVAL,
+             "dot_static: n = %lld is outside [0, %lld]", (long long)n, (long long)NALU_GPU_DOT_STATIC_MAX_N);
+  NG_REQUIRE(out_dev && (n == 0 || (a_dev && b_dev)), NALU_GPU_EINVAL, "dot_static: null device pointer");
+  int ndev = 0;
+  NG_HIP(hipGetDeviceCount(&ndev));
+  NG_REQUIRE(device >= 0 && device < ndev && device < DOT_STATIC_MAX_DEVICES, NALU_GPU_EINVAL,
+             "dot_static: device %d of %d", device, ndev);
+  NG_DEVICE(device);
+  double *scratch = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_dotScratchMutex);
+    if (!g_dotScratchPtr[device]) {  // first call on this device, with this device current
+      void *p = nullptr;
+      NG_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(dotScratch)));
+      NG_REQUIRE(p, NALU_GPU_EHIP, "dot_static: no device address for the scratch array");
+      g_dotScratchPtr[device] = (double *)p;
+    }
+    scratch = g_dotScratchPtr[device];
+  }
+  // the same two kernels, grid and summation order as nalu_gpu_dot: bit-identical result.  Every
+  // partial that the second stage reads is written by this call's first stage (vb of them), so
+  // nothing of an earlier call is left to clear.
+  const hipStream_t st = (hipStream_t)hip_stream;
+  const int vb = vec_grid(n);
+  k_dot<<<vb, 256, 0, st>>>(n, a_dev, b_dev, scratch);
+  k_reduce_partials<EPI_NONE><<<1, RED_T, 0, st>>>(scratch, vb, 1, out_dev, nullptr, nullptr);
+  NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
 }
 
