@@ -291,6 +291,9 @@ int nalu_gpu_project_nodal_velocity(nalu_gpu_linsys *h, int64_t n, double dt, do
 int nalu_gpu_set_halo_plan(nalu_gpu_linsys *h, int n_neighbors, const int *neighbor_ranks,
                            const int *send_offsets, const int *send_lids,
                            const int *recv_offsets);
+/* the plan as set: pointers into the handle (valid until the next set_halo_plan / destroy) */
+int nalu_gpu_get_halo_plan(nalu_gpu_linsys *h, int *n_neighbors, const int **neighbor_ranks,
+                           const int **send_offsets, const int **recv_offsets);
 typedef struct {
   void *ctx;
   /* in-place sum over ranks of count doubles at the handle's reduce buffer */

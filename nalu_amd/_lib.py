@@ -30,7 +30,7 @@ SYMBOLS = [
     "nalu_gpu_solve", "nalu_gpu_spmv", "nalu_gpu_dot", "nalu_gpu_axpy", "nalu_gpu_norm2",
     "nalu_gpu_compute_mdot_edges", "nalu_gpu_nodal_grad_edges",
     "nalu_gpu_field_axpby", "nalu_gpu_project_nodal_velocity", "nalu_gpu_compute_geometry_hex8", "nalu_gpu_set_halo_plan",
-    "nalu_gpu_set_comm", "nalu_gpu_set_callback_error", "nalu_gpu_get_comm_buffers", "nalu_gpu_halo_exchange",
+    "nalu_gpu_set_comm", "nalu_gpu_set_callback_error", "nalu_gpu_get_halo_plan", "nalu_gpu_get_comm_buffers", "nalu_gpu_halo_exchange",
     "nalu_gpu_set_profiling", "nalu_gpu_get_timer", "nalu_gpu_reset_timers",
     "nalu_gpu_synchronize", "nalu_gpu_get_layout_info", "nalu_gpu_dot_static",
 ]
@@ -149,6 +149,7 @@ def load():
         "nalu_gpu_set_halo_plan": [vp, ci, vp, vp, vp, vp],
         "nalu_gpu_set_comm": [vp, P(Comm)],
         "nalu_gpu_set_callback_error": [C.c_char_p],
+        "nalu_gpu_get_halo_plan": [vp, P(ci), P(vp), P(vp), P(vp)],
         "nalu_gpu_get_comm_buffers": [vp, P(vp), P(i64), P(vp), P(i64), P(vp), P(ci)],
         "nalu_gpu_halo_exchange": [vp, vp],
         "nalu_gpu_set_profiling": [vp, ci],

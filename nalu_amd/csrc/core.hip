@@ -1141,6 +1141,19 @@ extern "C" int nalu_gpu_set_halo_plan(nalu_gpu_linsys *h, int n_nbr, const int *
   return NALU_GPU_OK;
 }
 
+extern "C" int nalu_gpu_get_halo_plan(nalu_gpu_linsys *h, int *n_nbr, const int **nbr_ranks,
+                                      const int **send_offsets, const int **recv_offsets)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(h->nCols == h->nOwned || h->recvCount == h->nCols - h->nOwned, NALU_GPU_ESTATE,
+             "this system has %d shared/ghost columns and no halo plan yet", h->nCols - h->nOwned);
+  if (n_nbr) *n_nbr = h->nNbr;
+  if (nbr_ranks) *nbr_ranks = h->nbrRanks.data();
+  if (send_offsets) *send_offsets = h->sendOff.data();
+  if (recv_offsets) *recv_offsets = h->recvOff.data();
+  return NALU_GPU_OK;
+}
+
 extern "C" int nalu_gpu_set_comm(nalu_gpu_linsys *h, const nalu_gpu_comm *comm)
 {
   NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");

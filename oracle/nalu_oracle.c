@@ -723,6 +723,59 @@ static void continuity_edge(const int *en, const double *av, const double *xyz,
   if (tmdot_out) *tmdot_out = tmdot;
 }
 
+#ifdef _OPENMP
+/* CPU-baseline build only (-fopenmp).  One MPI rank of the reference owns its edges: it does not
+ * scan the other ranks' edges.  So every thread gets, once per edge list, the list of the edges
+ * that touch its contiguous block of rows ("owner computes": cut edges appear in two lists), in
+ * ascending edge order; building the lists is set-up (the mesh partition), not assembly. */
+static struct {
+  const int *edges; int64_t nedges; int nrows, nt;
+  int64_t *off;   /* nt + 1 */
+  int64_t *list;  /* edge ids, thread after thread */
+} g_buckets;
+
+void orc_omp_prepare_edge_buckets(const orc_linsys *ls, int64_t nedges, const int *edge_nodes)
+{
+  const int nt = omp_get_max_threads(), nrows = ls->maxOwnedRowId;
+  if (g_buckets.edges == edge_nodes && g_buckets.nedges == nedges && g_buckets.nrows == nrows &&
+      g_buckets.nt == nt)
+    return;
+  free(g_buckets.off); free(g_buckets.list);
+  g_buckets.edges = edge_nodes; g_buckets.nedges = nedges; g_buckets.nrows = nrows; g_buckets.nt = nt;
+  g_buckets.off = (int64_t *)calloc((size_t)nt + 1, sizeof(int64_t));
+  int64_t *cnt = (int64_t *)calloc((size_t)nt, sizeof(int64_t));
+#pragma omp parallel
+  {
+    const int t = omp_get_thread_num();
+    const int lo = (int)((int64_t)nrows * t / nt), hi = (int)((int64_t)nrows * (t + 1) / nt);
+    int64_t c = 0;
+    for (int64_t k = 0; k < nedges; ++k) {
+      const int L = edge_nodes[2 * k], R = edge_nodes[2 * k + 1];
+      c += (L >= lo && L < hi) || (R >= lo && R < hi);
+    }
+    cnt[t] = c;
+  }
+  for (int t = 0; t < nt; ++t) g_buckets.off[t + 1] = g_buckets.off[t] + cnt[t];
+  g_buckets.list = (int64_t *)malloc(sizeof(int64_t) * (size_t)(g_buckets.off[nt] > 0 ? g_buckets.off[nt] : 1));
+#pragma omp parallel
+  {
+    const int t = omp_get_thread_num();
+    const int lo = (int)((int64_t)nrows * t / nt), hi = (int)((int64_t)nrows * (t + 1) / nt);
+    int64_t *out = g_buckets.list + g_buckets.off[t];
+    for (int64_t k = 0; k < nedges; ++k) {
+      const int L = edge_nodes[2 * k], R = edge_nodes[2 * k + 1];
+      if ((L >= lo && L < hi) || (R >= lo && R < hi)) *out++ = k;
+    }
+  }
+  free(cnt);
+}
+#else
+void orc_omp_prepare_edge_buckets(const orc_linsys *ls, int64_t nedges, const int *edge_nodes)
+{
+  (void)ls; (void)nedges; (void)edge_nodes; /* single-thread builds walk the edge list itself */
+}
+#endif
+
 void orc_assemble_continuity_edges(orc_linsys *ls, int64_t nedges, const int *edge_nodes,
                                    const double *edge_area, const double *xyz,
                                    const double *dpdx, const double *vel,
@@ -733,19 +786,20 @@ void orc_assemble_continuity_edges(orc_linsys *ls, int64_t nedges, const int *ed
 #ifdef _OPENMP
   /* CPU-baseline build only (-fopenmp): every thread owns a contiguous block of rows and
    * assembles the edges that touch it, summing only its own rows. */
+  orc_omp_prepare_edge_buckets(ls, nedges, edge_nodes); /* no-op when bench.py prepared them */
 #pragma omp parallel
   {
-    const int nt = omp_get_num_threads(), t = omp_get_thread_num();
+    const int nt = g_buckets.nt, t = omp_get_thread_num();
     const int nrows = ls->maxOwnedRowId;
     const int lo = (int)((int64_t)nrows * t / nt), hi = (int)((int64_t)nrows * (t + 1) / nt);
     double lhs[4], rhs[2];
-    for (int64_t k = 0; k < nedges; ++k) {
-      const int L = edge_nodes[2 * k], R = edge_nodes[2 * k + 1];
-      if ((L < lo || L >= hi) && (R < lo || R >= hi)) continue;
-      continuity_edge(edge_nodes + 2 * k, edge_area + 3 * k, xyz, dpdx, vel, pressure, density,
-                      projTimeScale, nocFac, interpTogether, lhs, rhs, NULL);
-      sum_into_rows(ls, 2, edge_nodes + 2 * k, rhs, lhs, lo, hi);
-    }
+    if (t < nt)
+      for (int64_t i = g_buckets.off[t]; i < g_buckets.off[t + 1]; ++i) {
+        const int64_t k = g_buckets.list[i];
+        continuity_edge(edge_nodes + 2 * k, edge_area + 3 * k, xyz, dpdx, vel, pressure, density,
+                        projTimeScale, nocFac, interpTogether, lhs, rhs, NULL);
+        sum_into_rows(ls, 2, edge_nodes + 2 * k, rhs, lhs, lo, hi);
+      }
   }
 #else
   double lhs[4], rhs[2];
@@ -877,12 +931,31 @@ void orc_assemble_scalar_edges(orc_linsys *ls, int64_t nedges, const int *edge_n
                                const double *q, const double *density,
                                const double *diffFluxCoeff, const orc_scalar_opts *o)
 {
+#ifdef _OPENMP
+  /* CPU-baseline build only: owner-computes edge lists per thread, as for the continuity loop */
+  orc_omp_prepare_edge_buckets(ls, nedges, edge_nodes);
+#pragma omp parallel
+  {
+    const int nt = g_buckets.nt, t = omp_get_thread_num();
+    const int nrows = ls->maxOwnedRowId;
+    const int lo = (int)((int64_t)nrows * t / nt), hi = (int)((int64_t)nrows * (t + 1) / nt);
+    double lhs[4], rhs[2];
+    if (t < nt)
+      for (int64_t i = g_buckets.off[t]; i < g_buckets.off[t + 1]; ++i) {
+        const int64_t k = g_buckets.list[i];
+        scalar_edge(edge_nodes + 2 * k, edge_area + 3 * k, mdot[k], xyz, dqdx, vel, q, density,
+                    diffFluxCoeff, o, lhs, rhs);
+        sum_into_rows(ls, 2, edge_nodes + 2 * k, rhs, lhs, lo, hi);
+      }
+  }
+#else
   double lhs[4], rhs[2];
   for (int64_t k = 0; k < nedges; ++k) {
     scalar_edge(edge_nodes + 2 * k, edge_area + 3 * k, mdot[k], xyz, dqdx, vel, q, density,
                 diffFluxCoeff, o, lhs, rhs);
     orc_sum_into(ls, 2, edge_nodes + 2 * k, rhs, lhs); /* apply_coeff, :311 */
   }
+#endif
 }
 
 void orc_scalar_edge_coeffs(int64_t nedges, const int *edge_nodes, const double *edge_area,

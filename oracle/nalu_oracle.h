@@ -117,6 +117,9 @@ double orc_peclet_tanh(double c1, double c2, double x);
 double orc_van_leer(double dqm, double dqp, double small);
 
 /* src/AssembleContinuityEdgeSolverAlgorithm.C:74-209. All nodal arrays AoS as STK. */
+/* CPU-baseline (OpenMP) build: per-thread owner-computes edge lists, built once per edge list
+ * (set-up, like the mesh partition of an MPI run); a no-op in the single-thread builds */
+void orc_omp_prepare_edge_buckets(const orc_linsys *ls, int64_t nedges, const int *edge_nodes);
 void orc_assemble_continuity_edges(orc_linsys *ls, int64_t nedges, const int *edge_nodes,
                                    const double *edge_area, const double *xyz,
                                    const double *dpdx, const double *vel,

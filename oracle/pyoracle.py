@@ -105,6 +105,7 @@ def _bind(lib):
     lib.orc_van_leer.restype = C.c_double
     cont = [C.c_int64, _ip, _dp, _dp, _dp, _dp, _dp, _dp] + [C.c_double] * 4
     lib.orc_assemble_continuity_edges.argtypes = [C.POINTER(_LinSys)] + cont
+    lib.orc_omp_prepare_edge_buckets.argtypes = [C.POINTER(_LinSys), C.c_int64, _ip]
     lib.orc_continuity_edge_coeffs.argtypes = cont + [_dp, _dp]
     lib.orc_compute_mdot_edges.argtypes = cont + [_dp]
     scal = [C.c_int64, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(ScalarOpts)]
@@ -252,6 +253,12 @@ class LinSys:
     def solution(self):
         n = self.n_owned * self.num_dof
         return np.ctypeslib.as_array(self.p.contents.sln, shape=(max(n, 1),))[:n].copy()
+
+    def prepare_edge_buckets(self, edge_nodes):
+        """OpenMP flavour only: per-thread edge lists (set-up); edge_nodes must be the very array
+        (same memory) that the assemble_* calls get"""
+        assert edge_nodes.dtype == np.int32 and edge_nodes.flags["C_CONTIGUOUS"]
+        self.L.orc_omp_prepare_edge_buckets(self.p, edge_nodes.shape[0], edge_nodes)
 
     def assemble_continuity(self, edge_nodes, area, xyz, dpdx, vel, p, rho, dt, gamma1=1.0,
                             noc=1.0, interp=1.0):

@@ -1,0 +1,221 @@
+// gatherbench.hip -- what bounds the row-gather assembly's memory skeleton? (development aid)
+// 65536 workgroups of 256 threads over 256^3 nodes; workgroup s reads its own 256-node line of
+// nodal data and the four neighbour lines (s-1, s+1, s-256, s+256): the gathers of the assembly
+// row kernel without arithmetic.  57.7 M 128-byte lines per launch when the data are 11 arrays
+// of doubles.  Modes:
+//   0  11 SoA arrays of double, 8-byte loads (the shipped layout)
+//   1  3 arrays of double4 {x,y,z,p} {gx,gy,gz,rho} {ux,uy,uz,pad}: 16-byte loads, 2 per array
+//   2  6 arrays of double2: one 16-byte load per array
+//   3  mode 0, two rows per thread (128-thread workgroups, rows t and t+128)
+//   4  mode 0 + 18 area-vector loads + 8 stores per row (the whole skeleton)
+//   5  mode 1 + area as double4 per (row, slot) [6 loads of 32 B] + 8 stores
+//   6  mode 0 but neighbour lines staged through LDS by 16-byte loads (each thread loads 16 B
+//      = two rows of one field; reads its own row back from LDS)
+// Usage: gatherbench <mode> [occupancyLimiterLdsBytes]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+constexpr int NF = 11;
+struct Fields { const double *f[NF]; const double4 *q[3]; const double2 *d[6]; const double *area[3]; const double4 *area4; };
+
+__device__ __forceinline__ int xcd_run(int b, int n, int G)
+{
+  const int full = n / (8 * G) * (8 * G);
+  if (b >= full) return b;
+  const int xcd = b & 7, idx = b >> 3;
+  return ((idx / G) * 8 + xcd) * G + idx % G;
+}
+
+__device__ __forceinline__ long long clampRow(long long c, long long row, long long n) { return (c < 0 || c >= n) ? row : c; }
+
+template <int MODE>
+__global__ __launch_bounds__(MODE == 3 ? 128 : 256) void k(Fields F, int nSlices, double *out, double *big)
+{
+  extern __shared__ double dyn[];
+  const int s = xcd_run(blockIdx.x, nSlices, 8);
+  const long long n = (long long)nSlices * 256;
+  const long long ds[5] = {0, -256, 256, -256 * 256, 256 * 256};
+  double acc = 0.0;
+  if (MODE == 0 || MODE == 4) {
+    const long long row = (long long)s * 256 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const long long c = clampRow(row + ds[j], row, n);
+#pragma unroll
+      for (int i = 0; i < NF; ++i) acc += F.f[i][c];
+    }
+    if (MODE == 4) {
+      // slot-major edge ids: the + edges of a row are row, n + row, 2n + row; the - edges those of
+      // the neighbour rows
+      const long long nb[6] = {row, clampRow(row - 1, row, n), row, clampRow(row - 256, row, n), row,
+                               clampRow(row - 65536, row, n)};
+#pragma unroll
+      for (int e = 0; e < 6; ++e)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc += F.area[c][(e / 2) * n + nb[e]];
+      const long long base = (long long)s * 256 * 8 + threadIdx.x;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) big[base + j * 256] = acc + j;
+    }
+  } else if (MODE >= 64) {
+    constexpr int FL = MODE - 64;
+    const long long row = (long long)s * 256 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < ((FL & 1) ? 5 : 1); ++j) {
+      const long long c = clampRow(row + ds[j], row, n);
+#pragma unroll
+      for (int i = 0; i < NF; ++i) acc += F.f[i][c];
+    }
+    if (FL & 2) {
+      const long long nb[6] = {row, clampRow(row - 1, row, n), row, clampRow(row - 256, row, n), row,
+                               clampRow(row - 65536, row, n)};
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        if ((FL & 32) && (e & 1)) continue;
+        if ((FL & 16) && e == 1) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc += __shfl_up(F.area[c][row], 1, 64);
+          continue;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc += F.area[c][(e / 2) * n + nb[e]];
+      }
+    }
+    if (FL & 4) {
+      const long long base = (long long)s * 256 * 8 + threadIdx.x;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (FL & 8) __builtin_nontemporal_store(acc + j, big + base + j * 256);
+        else big[base + j * 256] = acc + j;
+      }
+    }
+  } else if (MODE == 1 || MODE == 5) {
+    const long long row = (long long)s * 256 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const long long c = clampRow(row + ds[j], row, n);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double4 v = F.q[i][c];
+        acc += v.x + v.y + v.z + v.w;
+      }
+    }
+    if (MODE == 5) {
+      const long long nb[6] = {row, clampRow(row - 1, row, n), row, clampRow(row - 256, row, n), row,
+                               clampRow(row - 65536, row, n)};
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const double4 v = F.area4[(e / 2) * n + nb[e]];
+        acc += v.x + v.y + v.z;
+      }
+      const long long base = (long long)s * 256 * 8 + threadIdx.x;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) big[base + j * 256] = acc + j;
+    }
+  } else if (MODE == 2) {
+    const long long row = (long long)s * 256 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const long long c = clampRow(row + ds[j], row, n);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double2 v = F.d[i][c];
+        acc += v.x + v.y;
+      }
+    }
+  } else if (MODE == 3) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long long row = (long long)s * 256 + threadIdx.x + h * 128;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const long long c = clampRow(row + ds[j], row, n);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) acc += F.f[i][c];
+      }
+    }
+  } else if (MODE == 6) {
+    // 5 lines x 11 fields x 256 doubles = 110 KB would not fit twice; stage one neighbour line at a
+    // time: 11 fields x 2 KB = 22 KB.  Thread t loads 16 B pieces: piece p = t + 256 q covers field
+    // p / 128, doubles 2 (p % 128) .. +1
+    double *lds = dyn;
+    const long long row = (long long)s * 256 + threadIdx.x;
+    for (int j = 0; j < 5; ++j) {
+      const long long c0 = clampRow((long long)s * 256 + ds[j], (long long)s * 256, n);
+      double2 v[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int p = threadIdx.x + 256 * q;
+        if (p < NF * 128) v[q] = *reinterpret_cast<const double2 *>(F.f[p / 128] + c0 + 2 * (p % 128));
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int p = threadIdx.x + 256 * q;
+        if (p < NF * 128) *reinterpret_cast<double2 *>(lds + (p / 128) * 256 + 2 * (p % 128)) = v[q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NF; ++i) acc += lds[i * 256 + threadIdx.x];
+    }
+    (void)row;
+  }
+  if (acc == 1.2345e300) out[0] = acc;
+}
+
+template <int MODE>
+void run(Fields F, int nSlices, double *out, double *big, size_t lds)
+{
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    CK(hipEventRecord(a));
+    k<MODE><<<nSlices, MODE == 3 ? 128 : 256, lds>>>(F, nSlices, out, big);
+    CK(hipEventRecord(b));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    if (rep >= 2 && ms < best) best = ms;
+  }
+  const double n = (double)nSlices * 256;
+  printf("mode %d lds %zu: %.3f ms  (5 lines x 88 B per row: %.1f lines/ns, own bytes %.2f TB/s)\n", MODE, lds, best,
+         n * 5 * 88 / 128 / (best * 1e6), n * 88 / best / 1e9);
+}
+
+int main(int argc, char **argv)
+{
+  const int mode = argc > 1 ? atoi(argv[1]) : 0;
+  size_t lds = argc > 2 ? (size_t)atol(argv[2]) : 0;
+  const int nSlices = 65536;
+  const long long n = (long long)nSlices * 256;
+  Fields F;
+  double *pool;
+  CK(hipMalloc(&pool, n * 8 * 12));
+  CK(hipMemset(pool, 0, n * 8 * 12));
+  for (int i = 0; i < NF; ++i) F.f[i] = pool + (long long)i * n;
+  for (int i = 0; i < 3; ++i) F.q[i] = reinterpret_cast<const double4 *>(pool + (long long)i * 4 * n);
+  for (int i = 0; i < 6; ++i) F.d[i] = reinterpret_cast<const double2 *>(pool + (long long)i * 2 * n);
+  double *ar;
+  CK(hipMalloc(&ar, n * 8 * 12));
+  CK(hipMemset(ar, 0, n * 8 * 12));
+  for (int c = 0; c < 3; ++c) F.area[c] = ar + (long long)c * 3 * n;
+  F.area4 = reinterpret_cast<const double4 *>(ar);
+  double *out, *big;
+  CK(hipMalloc(&out, 8));
+  CK(hipMalloc(&big, n * 8 * 8));
+  if (mode == 6 && lds < 22528) lds = 22528;
+  switch (mode) {
+    case 0: run<0>(F, nSlices, out, big, lds); break;
+    case 1: run<1>(F, nSlices, out, big, lds); break;
+    case 2: run<2>(F, nSlices, out, big, lds); break;
+    case 3: run<3>(F, nSlices, out, big, lds); break;
+    case 4: run<4>(F, nSlices, out, big, lds); break;
+    case 5: run<5>(F, nSlices, out, big, lds); break;
+    case 6: run<6>(F, nSlices, out, big, lds); break;
+#define C(m) case 64 + m: run<64 + m>(F, nSlices, out, big, lds); break;
+    C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(12) C(13) C(14) C(15) C(23) C(39) C(38) C(34) C(35)
+  }
+  return 0;
+}

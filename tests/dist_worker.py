@@ -90,7 +90,16 @@ def gpu_test(rank, world, method):
     g.buildEdgeToNodeGraph(S.edge_nodes)
     g.finalizeLinearSystem()
     g.set_halo_plan(S.neighbors, S.send_offsets, S.send_lids, S.recv_offsets)
-    comm = TorchComm(g, S.neighbors, S.send_offsets, S.recv_offsets, dev)
+    # NALU_TEST_NATIVE_RCCL=1: the callbacks are libnalu_gpu_rccl.so's (ncclAllReduce / grouped
+    # ncclSend+ncclRecv called straight from the library) instead of torch.distributed's
+    native = os.environ.get("NALU_TEST_NATIVE_RCCL") == "1"
+    if native:
+        from nalu_amd.rccl import RcclWorld
+        rworld = RcclWorld(rank, world, 0)
+        rworld.attach(g)
+        comm = type("NoErrors", (), {"errors": []})()
+    else:
+        comm = TorchComm(g, S.neighbors, S.send_offsets, S.recv_offsets, dev)
     # nodal inputs: owned values only, shared/ghost copies through the library's halo exchange
     def nodal(a):
         v = t(a[gi])
@@ -163,6 +172,8 @@ def gpu_test(rank, world, method):
     assert rel_err(x.cpu().numpy(), ref["x"][gi]) <= 1e-9
     assert abs(g.linearResidual - ref["final_resid"]) <= 1e-10
     assert abs(g.nonLinearResidual - np.linalg.norm(ls.owned_rhs())) <= 1e-12 * np.linalg.norm(ls.owned_rhs())
+    if native:
+        rworld.close()
     g.close()
 
 

@@ -35,6 +35,20 @@ def test_python_binding_table_matches_the_header():
     assert sorted(SYMBOLS) == declared_entry_points()
 
 
+def test_rccl_library_exports_its_header():
+    """include/nalu_gpu_rccl.h <-> libnalu_gpu_rccl.so <-> nalu_amd.rccl.SYMBOLS (no call made)"""
+    from nalu_amd import rccl
+    text = open(os.path.join(ROOT, "include", "nalu_gpu_rccl.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(nalu_gpu_rccl_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(rccl.SYMBOLS) and len(names) == 6
+    assert os.path.exists(rccl.RCCL_LIB_PATH), "libnalu_gpu_rccl.so is missing: run __graft_entry__.build()"
+    import torch  # noqa: F401  (its bundled HIP / RCCL runtime is the one the library binds to)
+    lib = C.CDLL(rccl.RCCL_LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
 def test_calls_that_need_no_device(lib):
     lib.nalu_gpu_version.restype = C.c_int
     lib.nalu_gpu_last_error.restype = C.c_char_p

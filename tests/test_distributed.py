@@ -8,9 +8,10 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _launch(nproc, *args, timeout=300, backend="gloo", side_stream=False):
+def _launch(nproc, *args, timeout=300, backend="gloo", side_stream=False, native_rccl=False):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", NALU_TEST_BACKEND=backend,
-               NALU_TEST_SIDE_STREAM="1" if side_stream else "0")
+               NALU_TEST_SIDE_STREAM="1" if side_stream else "0",
+               NALU_TEST_NATIVE_RCCL="1" if native_rccl else "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 500),
            os.path.join(HERE, "dist_worker.py"), *args]
@@ -46,6 +47,16 @@ def test_comm_on_a_non_default_stream(nproc, backend):
     the TorchComm callbacks switch to the library's stream, so halos and dot products are ordered
     after the kernels that produce them (same results as on the default stream)."""
     _launch(nproc, "gpu", "cg", backend=backend, side_stream=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,side_stream", [("cg", False), ("gmres", True)])
+def test_native_rccl_callbacks_world_1(method, side_stream):
+    """libnalu_gpu_rccl.so (include/nalu_gpu_rccl.h): unique id -> ncclCommInitRank -> callbacks
+    attached to the system; every reduction of the solves goes through ncclAllReduce called from
+    the library itself (no Python per iteration).  One rank per GPU, so world size 1 on the test
+    box; the grouped send/recv half needs the 8-GPU node (bench.py --gpus N uses this path)."""
+    _launch(1, "gpu", method, backend="nccl", side_stream=side_stream, native_rccl=True)
 
 
 @pytest.mark.gpu
