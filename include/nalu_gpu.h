@@ -223,6 +223,20 @@ typedef struct {
 int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, double *x_out_dev,
                    nalu_gpu_solve_info *info, double *history, int history_cap);
 
+/* checkForNaN + checkForZeroRow (src/TpetraLinearSystem.C:1782-1899) on the owned rows of this
+ * rank: rows with a NaN entry, NaN entries of the rhs, rows with sum |a_ij| < 1e-10 (:1862), and
+ * the smallest local row of each kind (-1: none). */
+typedef struct {
+  int64_t lhs_nan_rows, rhs_nan_rows, zero_rows;
+  int64_t first_lhs_nan_row, first_rhs_nan_row, first_zero_row;
+} nalu_gpu_check_info;
+int nalu_gpu_check_system(nalu_gpu_linsys *h, nalu_gpu_check_info *info);
+/* realm_.debug() (src/TpetraLinearSystem.C:1716-1721): when on, nalu_gpu_solve runs the two checks
+ * first and fails with NALU_GPU_EINVAL ("bad LHS" / "ERROR checkForZeroRow in solve()") instead of
+ * solving.  Independently of this switch a zero, missing or non-finite diagonal under a
+ * relaxation preconditioner is always an error (single rank), never a silent inf. */
+int nalu_gpu_set_debug(nalu_gpu_linsys *h, int enabled);
+
 /* ---- building blocks exposed for measurement and parity (Tpetra call sites:
  * matrix_->apply src/LinearSolver.C:164, update :166, norm2 :172) */
 int nalu_gpu_spmv(nalu_gpu_linsys *h, const double *x_dev /* n_cols */, double *y_dev /* n_rows */);

@@ -32,7 +32,7 @@ SYMBOLS = [
     "nalu_gpu_field_axpby", "nalu_gpu_project_nodal_velocity", "nalu_gpu_compute_geometry_hex8", "nalu_gpu_set_halo_plan",
     "nalu_gpu_set_comm", "nalu_gpu_set_callback_error", "nalu_gpu_get_halo_plan", "nalu_gpu_get_comm_buffers", "nalu_gpu_halo_exchange",
     "nalu_gpu_set_profiling", "nalu_gpu_get_timer", "nalu_gpu_reset_timers",
-    "nalu_gpu_synchronize", "nalu_gpu_get_layout_info", "nalu_gpu_dot_static",
+    "nalu_gpu_synchronize", "nalu_gpu_get_layout_info", "nalu_gpu_check_system", "nalu_gpu_set_debug", "nalu_gpu_dot_static",
 ]
 
 
@@ -67,6 +67,11 @@ class SolveInfo(C.Structure):
     _fields_ = [("iters", C.c_int), ("final_resid", C.c_double), ("rhs_norm2", C.c_double),
                 ("precond_seconds", C.c_double), ("solve_seconds", C.c_double),
                 ("history_len", C.c_int)]
+
+
+class CheckInfo(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("lhs_nan_rows", "rhs_nan_rows", "zero_rows", "first_lhs_nan_row",
+                                          "first_rhs_nan_row", "first_zero_row")]
 
 
 class LayoutInfo(C.Structure):
@@ -157,6 +162,8 @@ def load():
         "nalu_gpu_reset_timers": [vp],
         "nalu_gpu_synchronize": [vp],
         "nalu_gpu_get_layout_info": [vp, P(LayoutInfo)],
+        "nalu_gpu_check_system": [vp, P(CheckInfo)],
+        "nalu_gpu_set_debug": [vp, ci],
         "nalu_gpu_dot_static": [ci, vp, vp, vp, i64, vp],
     }
     for name, args in sig.items():

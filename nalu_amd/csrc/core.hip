@@ -730,7 +730,7 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
     NG_HIP(hipMalloc(&h->dSliceLists, sizeof(int) * (size_t)h->nSlices));
     NG_HIP(hipMemcpy(h->dSliceLists, lists.data(), sizeof(int) * (size_t)h->nSlices, hipMemcpyHostToDevice));
   }
-  NG_HIP(hipMalloc(&h->dReduce, sizeof(double) * REDUCE_CAP));
+  NG_HIP(hipMalloc(&h->dReduce, sizeof(double) * (REDUCE_CAP + 8)));  // + 8 ints of error counters
   NG_HIP(hipMalloc(&h->dScal, sizeof(SolverScalars)));
   NG_HIP(hipHostMalloc(&h->hPinned, 4096, hipHostMallocDefault));
   NG_HIP(hipMemsetAsync(h->dRhs, 0, sizeof(double) * nR, h->stream));

@@ -144,6 +144,7 @@ struct nalu_gpu_linsys {
   double *dX = nullptr;     // nCols
   double *dDinv = nullptr;  // nCols
   bool lazyZero = false;
+  bool debug = false;  // realm_.debug(): checkForNaN / checkForZeroRow before every solve
 
   // solver workspace
   double *dR = nullptr, *dP = nullptr, *dQ = nullptr, *dW = nullptr, *dT = nullptr;

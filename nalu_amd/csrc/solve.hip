@@ -339,18 +339,49 @@ __global__ __launch_bounds__(256) void k_axpy(long long n, double alpha, const d
 // dinv = 1/diag(A) (Ifpack2 Jacobi compute(): diagonal extraction), or 1 without precond.
 // diagPos holds the SELL position of every row's diagonal entry (-1: none), found once at
 // finalize, so this reads one value per row instead of scanning the row's tags.
+// bad[0] counts the rows whose diagonal is missing, zero or not finite (dinv would be inf / NaN
+// and poison the whole solve without a word), bad[1] holds the smallest such row + 1.
 __global__ __launch_bounds__(256) void k_extract_dinv(int nRows, const long long *__restrict__ diagPos,
                                                        const double *__restrict__ vals, int jacobi,
-                                                       double *__restrict__ dinv)
+                                                       double *__restrict__ dinv, int *__restrict__ bad)
 {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= nRows) return;
   double d = 1.0;
   if (jacobi) {
     const long long pos = diagPos[row];
-    d = 1.0 / (pos >= 0 ? vals[pos] : 0.0);
+    const double a = pos >= 0 ? vals[pos] : 0.0;
+    d = 1.0 / a;
+    if (!(a != 0.0) || !(fabs(a) <= 1.79769313486231570e308)) {  // zero, NaN or inf
+      atomicAdd(bad, 1);
+      atomicMax(bad + 1, nRows - row);  // (max of n - row = the smallest row)
+    }
   }
   dinv[row] = d;
+}
+
+// checkForNaN + checkForZeroRow (src/TpetraLinearSystem.C:1782-1899), one thread per owned row:
+// out[0] rows with a NaN in the matrix, out[1] NaN entries of the rhs, out[2] rows with
+// sum |a_ij| < 1e-10 (:1862); out[3..5] the smallest row of each kind, stored as n - row
+__global__ __launch_bounds__(SELL_C) void k_check_rows(SellView A, const double *__restrict__ rhs, int *out)
+{
+  const int slice = blockIdx.x, r = threadIdx.x;
+  const int row = slice * SELL_C + r;
+  if (row >= A.nRows) return;
+  const long long off = A.sliceOff[slice];
+  const int w = A.sliceWidth[slice];
+  bool nan = false;
+  double sum = 0.0;
+  for (int k = 0; k < w; ++k) {
+    const long long pos = off + (long long)k * SELL_C + r;
+    if (A.tags[pos] == TAG_PAD) continue;
+    const double v = A.vals[pos];
+    nan |= v != v;
+    sum += fabs(v);
+  }
+  if (nan) { atomicAdd(out, 1); atomicMax(out + 3, A.nRows - row); }
+  if (rhs[row] != rhs[row]) { atomicAdd(out + 1, 1); atomicMax(out + 4, A.nRows - row); }
+  if (!nan && sum < 1.e-10) { atomicAdd(out + 2, 1); atomicMax(out + 5, A.nRows - row); }
 }
 
 // ------------------------------------------------------------------- Chebyshev
@@ -1342,6 +1373,34 @@ extern "C" int nalu_gpu_axpy(nalu_gpu_linsys *h, double alpha, const double *x, 
   return NALU_GPU_OK;
 }
 
+extern "C" int nalu_gpu_check_system(nalu_gpu_linsys *h, nalu_gpu_check_info *info)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(info, NALU_GPU_EINVAL, "info is null");
+  NG_TRY(materialize_zero(h));
+  int *dOut = (int *)(h->dReduce + REDUCE_CAP);
+  NG_HIP(hipMemsetAsync(dOut, 0, 8 * sizeof(int), h->stream));
+  if (h->nSlices) k_check_rows<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), h->dRhs, dOut);
+  NG_HIP(hipGetLastError());
+  int *o = (int *)((char *)h->hPinned + 3072);
+  NG_HIP(hipMemcpyAsync(o, dOut, 6 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  NG_HIP(hipStreamSynchronize(h->stream));
+  info->lhs_nan_rows = o[0];
+  info->rhs_nan_rows = o[1];
+  info->zero_rows = o[2];
+  info->first_lhs_nan_row = o[0] ? h->nOwned - o[3] : -1;
+  info->first_rhs_nan_row = o[1] ? h->nOwned - o[4] : -1;
+  info->first_zero_row = o[2] ? h->nOwned - o[5] : -1;
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_set_debug(nalu_gpu_linsys *h, int enabled)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  h->debug = enabled != 0;
+  return NALU_GPU_OK;
+}
+
 extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, double *x_out_dev,
                               nalu_gpu_solve_info *info, double *history, int history_cap)
 {
@@ -1357,23 +1416,49 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
              "names, src/LinearSolverConfig.C:97-99)", cfg->precond);
   NG_REQUIRE(cfg->max_iterations >= 0 && cfg->tolerance >= 0.0, NALU_GPU_EINVAL, "bad solver limits");
   NG_TRY(materialize_zero(h));
+  if (h->debug) {  // realm_.debug() (src/TpetraLinearSystem.C:1716-1721)
+    nalu_gpu_check_info ci;
+    NG_TRY(nalu_gpu_check_system(h, &ci));
+    NG_REQUIRE(ci.lhs_nan_rows == 0 && ci.rhs_nan_rows == 0, NALU_GPU_EINVAL,
+               "bad %s: NaN in local row %lld (checkForNaN, src/TpetraLinearSystem.C:1782-1810)",
+               ci.lhs_nan_rows ? "LHS" : "RHS", (long long)(ci.lhs_nan_rows ? ci.first_lhs_nan_row : ci.first_rhs_nan_row));
+    NG_REQUIRE(ci.zero_rows == 0, NALU_GPU_EINVAL,
+               "ERROR checkForZeroRow in solve(): %lld row(s) with sum |a_ij| < 1e-10, first local row %lld",
+               (long long)ci.zero_rows, (long long)ci.first_zero_row);
+  }
   const int checkEvery = cfg->check_every > 0 ? cfg->check_every : 10;
   NG_TRY(ensure_hist(h, cfg->max_iterations + 2));
 
   // preconditioner_->compute() (src/LinearSolver.C:205), timed like timerPrecond_ (:195-211)
   const auto t0 = std::chrono::steady_clock::now();
   timer_begin(h, NALU_GPU_T_PRECOND);
+  int *dBad = (int *)(h->dReduce + REDUCE_CAP);  // 8 ints behind the reduce buffer
+  NG_HIP(hipMemsetAsync(dBad, 0, 8 * sizeof(int), h->stream));
   if (h->nOwned)
     k_extract_dinv<<<(h->nOwned + 255) / 256, 256, 0, h->stream>>>(h->nOwned, h->dDiagPos, h->dVals,
                                                                    cfg->precond != NALU_GPU_PRECOND_NONE,
-                                                                   h->dDinv);
+                                                                   h->dDinv, dBad);
   if (cfg->precond == NALU_GPU_PRECOND_SGS) NG_TRY(ensure_sgs_levels(h));
   if (cfg->precond == NALU_GPU_PRECOND_MT_SGS) NG_TRY(ensure_mc_colors(h));
   NG_HIP(hipGetLastError());
   NG_TRY(halo_exchange(h, h->dDinv));
   if (cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV) NG_TRY(cheb_compute(h));
   timer_end(h, NALU_GPU_T_PRECOND);
-  NG_HIP(hipStreamSynchronize(h->stream));
+  {
+    int *bad = (int *)((char *)h->hPinned + 3072);
+    NG_HIP(hipMemcpyAsync(bad, dBad, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    NG_HIP(hipStreamSynchronize(h->stream));
+    // every rank must leave together (the solve is collective): the verdict is all-reduced below
+    // only when a comm is set; a lone rank just reports
+    if (bad[0] > 0 && !h->hasComm) {
+      const int row = h->nOwned - bad[1];
+      return set_error(NALU_GPU_EINVAL,
+                       "%d row(s) have a zero, missing or non-finite diagonal (first: local row %d, global id "
+                       "%lld): the %s preconditioner cannot be built (Ifpack2 would produce inf; "
+                       "checkForZeroRow, src/TpetraLinearSystem.C:1716-1721, catches it in debug runs)",
+                       bad[0], row, (long long)h->gids[row], "relaxation");
+    }
+  }
   const auto t1 = std::chrono::steady_clock::now();
 
   timer_begin(h, NALU_GPU_T_SOLVE);

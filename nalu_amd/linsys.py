@@ -210,6 +210,16 @@ class GpuLinearSystem:
         L.check(self.lib.nalu_gpu_get_layout_info(self.h, C.byref(li)))
         return {k: getattr(li, k) for k, _ in li._fields_}
 
+    def check_system(self):
+        """checkForNaN / checkForZeroRow (src/TpetraLinearSystem.C:1782-1899) as a dict"""
+        ci = L.CheckInfo()
+        L.check(self.lib.nalu_gpu_check_system(self.h, C.byref(ci)))
+        return {k: getattr(ci, k) for k, _ in ci._fields_}
+
+    def set_debug(self, on=True):
+        """realm_.debug(): run the checks before every solve and fail instead of solving"""
+        L.check(self.lib.nalu_gpu_set_debug(self.h, int(on)))
+
     # ---- MatrixMarket dumps (src/TpetraLinearSystem.C:1901-1924, 2002-2019) -----
     def writeToFile(self, base_filename, useOwned=True, eq_sys_name="", n_ranks=1,
                     n_global=None):

@@ -856,3 +856,42 @@ def test_get_dof_status(G, oracle):
             assert sorted(s for _, s, _ in v) == [DS_OwnedDOF, DS_SharedNotOwnedDOF]
             owner = [r for r, s, _ in v if s == DS_OwnedDOF][0]
             assert all(o == owner for _, _, o in v)
+
+
+def test_diagnostics_zero_diagonal_nan_and_zero_row(G, torch, oracle):
+    """checkForNaN / checkForZeroRow (src/TpetraLinearSystem.C:1716-1721, 1782-1899) and the
+    zero-diagonal guard: a row without a usable diagonal is a loud error under a relaxation
+    preconditioner, never a silent inf; debug mode refuses to solve a system with a NaN or an
+    all-zero row."""
+    c = Case(oracle, 6, 0.125)
+    d = c.dev(torch)
+    g = c.gpu_system(G.GpuLinearSystem)
+    g.assemble_continuity_edges(d["coords"], d["dpdx"], d["vel"], d["p"], d["rho"], d["area"], c.dt)
+    assert g.check_system() == dict(lhs_nan_rows=0, rhs_nan_rows=0, zero_rows=0, first_lhs_nan_row=-1,
+                                    first_rhs_nan_row=-1, first_zero_row=-1)
+    g.resetRows([7, 100])  # FixPressureAtNode without its sumInto: rows 7 and 100 are all zero
+    ci = g.check_system()
+    assert ci["zero_rows"] == 2 and ci["first_zero_row"] == 7 and ci["lhs_nan_rows"] == 0
+    cfg = G.LinearSolverConfig(method="cg", preconditioner="jacobi", max_iterations=5)
+    with pytest.raises(G.NaluGpuError, match="diagonal.*local row 7"):
+        g.solve(cfg)
+    g.solve(G.LinearSolverConfig(method="cg", preconditioner="none", max_iterations=5))  # no diagonal needed
+    g.set_debug(True)
+    with pytest.raises(G.NaluGpuError, match="checkForZeroRow"):
+        g.solve(G.LinearSolverConfig(method="cg", preconditioner="none", max_iterations=5))
+    g.sumInto([7], [0.0], [1.0])
+    g.sumInto([100], [0.0], [1.0])
+    g.solve(cfg)  # healthy again
+    v = g.matrix_values()
+    v[11] = np.nan
+    g.set_matrix_values(v)
+    ci = g.check_system()
+    rp, _ = g.graph()
+    assert ci["lhs_nan_rows"] == 1 and ci["first_lhs_nan_row"] == np.searchsorted(rp, 11, side="right") - 1
+    with pytest.raises(G.NaluGpuError, match="bad LHS"):
+        g.solve(cfg)
+    g.set_debug(False)
+    b = g.rhs()
+    b[3] = np.nan
+    g.set_rhs(b)
+    assert g.check_system()["rhs_nan_rows"] == 1 and g.check_system()["first_rhs_nan_row"] == 3
