@@ -50,6 +50,7 @@ public:
     table_.allreduce_sum = &RcclComm::allreduce;
     table_.exchange_begin = &RcclComm::begin;
     table_.exchange_end = &RcclComm::end;
+    table_.exchange_rows = &RcclComm::rows;
     if (nalu_gpu_set_comm(h, &table_) != NALU_GPU_OK)
       throw std::runtime_error(std::string("RcclComm: ") + nalu_gpu_last_error());
   }
@@ -98,6 +99,21 @@ private:
     RcclComm *c = static_cast<RcclComm *>(ctx);
     if (c->nbr_.empty()) return 0;
     return hipStreamWaitEvent((hipStream_t)stream, c->arrived_, 0) == hipSuccess ? 0 : 1;
+  }
+
+  // loadComplete's row export (export mode): grouped send / recv of caller-given buffers, on the
+  // library's own stream (nothing to overlap with)
+  static int rows(void *ctx, const double *send, const int64_t *so, double *recv, const int64_t *ro, void *stream)
+  {
+    RcclComm *c = static_cast<RcclComm *>(ctx);
+    if (c->nbr_.empty()) return 0;
+    bool ok = ncclGroupStart() == ncclSuccess;
+    for (size_t p = 0; ok && p < c->nbr_.size(); ++p) {
+      const size_t ns = (size_t)(so[p + 1] - so[p]), nr = (size_t)(ro[p + 1] - ro[p]);
+      if (ns) ok = ncclSend(send + so[p], ns, ncclDouble, c->nbr_[p], c->comm_, (hipStream_t)stream) == ncclSuccess;
+      if (ok && nr) ok = ncclRecv(recv + ro[p], nr, ncclDouble, c->nbr_[p], c->comm_, (hipStream_t)stream) == ncclSuccess;
+    }
+    return (ncclGroupEnd() == ncclSuccess) && ok ? 0 : 1;
   }
 
   ncclComm_t comm_;

@@ -55,6 +55,26 @@ int nalu_gpu_version(void);
 int nalu_gpu_create(nalu_gpu_linsys **out, int device, int num_dof, void *hip_stream);
 int nalu_gpu_destroy(nalu_gpu_linsys *h);
 
+/* How rows of shared-not-owned nodes are handled.
+ * OWNER_COMPUTES (default): they are not stored; every rank assembles all entities that touch its
+ *   owned rows (cut edges are passed on both sides), loadComplete moves nothing, results do not
+ *   depend on the rank count.  A host sumInto that names a shared-not-owned row is an error
+ *   (NALU_GPU_EUNSUPPORTED): nothing is dropped silently.
+ * EXPORT_SHARED_ROWS: the reference's scheme (src/TpetraLinearSystem.C:1495-1505, 1686-1707): every
+ *   entity is assembled on ONE rank (its owner); contributions to rows of shared-not-owned nodes
+ *   go to local copies of those rows (sharedNotOwnedMatrix_) and nalu_gpu_load_complete sends
+ *   them to the owners, which add them (Tpetra Export, ADD).  The GRAPH still needs every edge
+ *   that touches an owned node (the reference exchanges the graph rows at finalize, :700-738);
+ *   nalu_gpu_set_edge_ownership then says which edges this rank assembles.  Needs a comm with
+ *   exchange_rows.  Call before nalu_gpu_begin_construction. */
+enum { NALU_GPU_ASSEMBLY_OWNER_COMPUTES = 0, NALU_GPU_ASSEMBLY_EXPORT_SHARED_ROWS = 1 };
+int nalu_gpu_set_assembly_mode(nalu_gpu_linsys *h, int mode);
+/* export mode: locally_owned[e] != 0 for the edges (in graph edge order, all edge blocks
+ * registered so far) that this rank assembles (the reference's locally_owned selector,
+ * src/AssembleContinuityEdgeSolverAlgorithm.C:115-117); the others only shape the graph.
+ * Call after the edge graph builders and before nalu_gpu_finalize; default: all owned. */
+int nalu_gpu_set_edge_ownership(nalu_gpu_linsys *h, int64_t n_edges, const unsigned char *locally_owned);
+
 /* ---- graph construction -------------------------------------------------------------
  * beginLinearSystemConstruction (src/TpetraLinearSystem.C:162-302). gids/owner_ranks have
  * n_owned+n_shared+n_ghost entries in local order; the ordering rules above are checked. */
@@ -192,7 +212,9 @@ int nalu_gpu_apply_dirichlet(nalu_gpu_linsys *h, int64_t n_nodes, const int *nod
                              const double *solution_dev, const double *bc_values_dev);
 /* resetRows (src/TpetraLinearSystem.C:1638-1684) */
 int nalu_gpu_reset_rows(nalu_gpu_linsys *h, int64_t n_nodes, const int *node_lids);
-/* loadComplete (src/TpetraLinearSystem.C:1686-1707) */
+/* loadComplete (src/TpetraLinearSystem.C:1686-1707): owner-computes mode has nothing to move;
+ * export mode packs the shared-not-owned rows (values + rhs), exchanges them and adds them to
+ * the owners' rows in neighbour order (deterministic).  Collective in export mode. */
 int nalu_gpu_load_complete(nalu_gpu_linsys *h);
 
 /* ---- solve ---------------------------------------------------------------------------
@@ -316,6 +338,12 @@ typedef struct {
    * before completion; end makes hip_stream wait for the received data) */
   int (*exchange_begin)(void *ctx, void *hip_stream);
   int (*exchange_end)(void *ctx, void *hip_stream);
+  /* optional (NULL: export mode is refused): neighbour exchange of other buffers than the halo's
+   * -- the row export of loadComplete.  For neighbour p (order of the halo plan) send the doubles
+   * send_dev[send_off[p] .. send_off[p+1]) and receive recv_dev[recv_off[p] .. recv_off[p+1]);
+   * work enqueued on hip_stream afterwards sees the received data. */
+  int (*exchange_rows)(void *ctx, const double *send_dev, const int64_t *send_off, double *recv_dev,
+                       const int64_t *recv_off, void *hip_stream);
 } nalu_gpu_comm;
 int nalu_gpu_set_comm(nalu_gpu_linsys *h, const nalu_gpu_comm *comm);
 /* A callback that fails (returns non-zero) may first leave a message here; the library appends

@@ -30,7 +30,7 @@ SYMBOLS = [
     "nalu_gpu_solve", "nalu_gpu_spmv", "nalu_gpu_dot", "nalu_gpu_axpy", "nalu_gpu_norm2",
     "nalu_gpu_compute_mdot_edges", "nalu_gpu_nodal_grad_edges",
     "nalu_gpu_field_axpby", "nalu_gpu_project_nodal_velocity", "nalu_gpu_compute_geometry_hex8", "nalu_gpu_set_halo_plan",
-    "nalu_gpu_set_comm", "nalu_gpu_set_callback_error", "nalu_gpu_get_halo_plan", "nalu_gpu_get_comm_buffers", "nalu_gpu_halo_exchange",
+    "nalu_gpu_set_comm", "nalu_gpu_set_callback_error", "nalu_gpu_get_halo_plan", "nalu_gpu_set_assembly_mode", "nalu_gpu_set_edge_ownership", "nalu_gpu_get_comm_buffers", "nalu_gpu_halo_exchange",
     "nalu_gpu_set_profiling", "nalu_gpu_get_timer", "nalu_gpu_reset_timers",
     "nalu_gpu_synchronize", "nalu_gpu_get_layout_info", "nalu_gpu_check_system", "nalu_gpu_set_debug", "nalu_gpu_dot_static",
 ]
@@ -82,11 +82,14 @@ class LayoutInfo(C.Structure):
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+EXCHANGE_ROWS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p,
+                               C.POINTER(C.c_int64), C.c_void_p)
 
 
 class Comm(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("allreduce_sum", ALLREDUCE_FN),
-                ("exchange_begin", EXCHANGE_FN), ("exchange_end", EXCHANGE_FN)]
+                ("exchange_begin", EXCHANGE_FN), ("exchange_end", EXCHANGE_FN),
+                ("exchange_rows", EXCHANGE_ROWS_FN)]
 
 
 _lib = None
@@ -155,6 +158,8 @@ def load():
         "nalu_gpu_set_comm": [vp, P(Comm)],
         "nalu_gpu_set_callback_error": [C.c_char_p],
         "nalu_gpu_get_halo_plan": [vp, P(ci), P(vp), P(vp), P(vp)],
+        "nalu_gpu_set_assembly_mode": [vp, ci],
+        "nalu_gpu_set_edge_ownership": [vp, i64, vp],
         "nalu_gpu_get_comm_buffers": [vp, P(vp), P(i64), P(vp), P(i64), P(vp), P(ci)],
         "nalu_gpu_halo_exchange": [vp, vp],
         "nalu_gpu_set_profiling": [vp, ci],

@@ -72,7 +72,8 @@ class TorchComm:
         self._ar = L.ALLREDUCE_FN(self._allreduce)
         self._xb = L.EXCHANGE_FN(self._exchange_begin)
         self._xe = L.EXCHANGE_FN(self._exchange_end)
-        self.struct = L.Comm(None, self._ar, self._xb, self._xe)
+        self._xr = L.EXCHANGE_ROWS_FN(self._exchange_rows)
+        self.struct = L.Comm(None, self._ar, self._xb, self._xe, self._xr)
         linsys.set_comm(self.struct)
 
     def _make_ops(self, send, recv):
@@ -144,6 +145,28 @@ class TorchComm:
                 self.pending = []
                 if self.stage:
                     self.recv.copy_(self._recv_host)
+            return 0
+        except Exception as e:  # pragma: no cover
+            return self._fail(e)
+
+    def _exchange_rows(self, ctx, send_ptr, send_off, recv_ptr, recv_off, stream):
+        """loadComplete's row export (export mode): caller-given device buffers, offsets per neighbour"""
+        try:
+            with self._on(stream):
+                nn = len(self.neighbors)
+                so = [int(send_off[p]) for p in range(nn + 1)]
+                ro = [int(recv_off[p]) for p in range(nn + 1)]
+                send = wrap_device(send_ptr, so[-1], self.device)
+                recv = wrap_device(recv_ptr, ro[-1], self.device)
+                if self.stage:
+                    hs, hr = send.cpu(), torch.empty(ro[-1], dtype=torch.float64)
+                    for w in exchange_halo(hs, hr, self.neighbors, so, ro, self.group):
+                        w.wait()
+                    if ro[-1]:
+                        recv.copy_(hr)
+                else:
+                    for w in exchange_halo(send, recv, self.neighbors, so, ro, self.group):
+                        w.wait()
             return 0
         except Exception as e:  # pragma: no cover
             return self._fail(e)

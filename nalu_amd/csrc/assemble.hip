@@ -285,7 +285,7 @@ __global__ __launch_bounds__(SELL_C, ORDERED ? Op::kOrderedWaves : 1) void k_ass
       const bool early = i < 8 && ((ow >> (24 + i)) & 1u);
       const long long pos = off + (long long)k * SELL_C + r;
       const unsigned tag = exT ? A.tags[pos] : tBase[k] + tMul[k] * (unsigned)row;
-      const bool isEdge = tag < TAG_OTHER;
+      const bool isEdge = tag < TAG_OTHER && (!A.edgeOwned || A.edgeOwned[tag & 0x7FFFFFFFu]);
       typename Op::Edge E;
       int c = row;
       bool inS = false;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(SELL_C, ORDERED ? Op::kOrderedWaves : 1) void k_ass
       } else if (tag == TAG_DIAG) {
         diagPos = pos;
       } else if (SET) {
-        A.vals[pos] = 0.0;
+        A.vals[pos] = 0.0;  // (padding, a non-edge graph entry, or an edge another rank assembles)
       }
       if (early) {
         if (nSt == 0) { stK0 = k; sV0 = isEdge; }
@@ -345,9 +345,9 @@ __global__ __launch_bounds__(SELL_C, ORDERED ? Op::kOrderedWaves : 1) void k_ass
     for (int k = 0; k < w; ++k) {
       const long long pos = off + (long long)k * SELL_C + r;
       const unsigned tag = exT ? A.tags[pos] : tBase[k] + tMul[k] * (unsigned)row;
-      if (tag >= TAG_OTHER) {
+      if (tag >= TAG_OTHER || (A.edgeOwned && !A.edgeOwned[tag & 0x7FFFFFFFu])) {
         if (tag == TAG_DIAG) diagPos = pos;
-        else if (SET) A.vals[pos] = 0.0;
+        else if (SET) A.vals[pos] = 0.0;  // (an edge another rank assembles counts as no edge)
         continue;
       }
       const int c = ex ? A.cols[pos] : row + kOff[k];
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(QROWS * NW) void k_assemble_entries(SellView A, typ
     if (live && k < w) {
       pos = off + (long long)k * SELL_C + q * QROWS + lane;
       tag = exT ? A.tags[pos] : tBase[k] + tMul[k] * (unsigned)row;
-      isEdge = tag < TAG_OTHER;
+      isEdge = tag < TAG_OTHER && (!A.edgeOwned || A.edgeOwned[tag & 0x7FFFFFFFu]);
       if (isEdge) {
         c = ex ? A.cols[pos] : row + kOff[k];
         inQ = (unsigned)(c - qBase) < (unsigned)nLive;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(QROWS * NW) void k_assemble_entries(SellView A, typ
         if (live) {
           pos = off + (long long)k * SELL_C + q * QROWS + lane;
           tag = exT ? A.tags[pos] : tBase[k] + tMul[k] * (unsigned)row;
-          isEdge = tag < TAG_OTHER;
+          isEdge = tag < TAG_OTHER && (!A.edgeOwned || A.edgeOwned[tag & 0x7FFFFFFFu]);
           if (isEdge) {
             c = ex ? A.cols[pos] : row + kOff[k];
             inQ = (unsigned)(c - qBase) < (unsigned)nLive;
@@ -537,11 +537,13 @@ __global__ __launch_bounds__(256) void k_assemble_edges(long long n, long long f
                                                          const int *__restrict__ eR,
                                                          const int *__restrict__ slots,
                                                          long long nEdges, typename Op::Params P,
-                                                         double *vals, double *rhs)
+                                                         double *vals, double *rhs,
+                                                         const unsigned char *__restrict__ edgeOwned)
 {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const long long e = perm ? perm[first + t] : first + t;
+  if (edgeOwned && !edgeOwned[e]) return;  // export mode: another rank assembles this edge
   const int L = eL[e], R = eR[e];
   const typename Op::Node nL = Op::load(P, L), nR = Op::load(P, R);
   double lhs[4], rh[2];
@@ -584,15 +586,15 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
       NG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
       int grid = std::max(1, perCu) * std::max(1, cus);
       grid = std::min((grid + 7) / 8 * 8, (nQ + 7) / 8 * 8);
-      kern<<<grid, QROWS * 8, 0, h->stream>>>(sell_view(h), P, h->dRhs);
+      kern<<<grid, QROWS * 8, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
     } else if (h->asmVariant == 2) {
       // NG_ASM_ORDER=1: the slice's out-of-slice entries first (k_slice_order).  HBM traffic falls
       // from 7.3 to 4.7 GB per launch at 256^3, but the 18 extra registers cost a wave per SIMD
       // and the kernel then sits on the L2 -> L1 bandwidth: 1.48 against 1.25 ms.
-      if (set) k_assemble_rows<Op, true, true><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), P, h->dRhs);
-      else k_assemble_rows<Op, false, true><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), P, h->dRhs);
-    } else if (set) k_assemble_rows<Op, true, false><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), P, h->dRhs);
-    else k_assemble_rows<Op, false, false><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), P, h->dRhs);
+      if (set) k_assemble_rows<Op, true, true><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+      else k_assemble_rows<Op, false, true><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+    } else if (set) k_assemble_rows<Op, true, false><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+    else k_assemble_rows<Op, false, false><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
     timer_end(h, NALU_GPU_T_ASSEMBLE_EDGES);
     NG_HIP(hipGetLastError());
     return NALU_GPU_OK;
@@ -602,7 +604,7 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
   if (mode == NALU_GPU_SCATTER_ATOMIC) {
     timer_begin(h, NALU_GPU_T_ASSEMBLE_EDGES);
     k_assemble_edges<Op, true><<<(unsigned)((h->nEdges + 255) / 256), 256, 0, h->stream>>>(
-        h->nEdges, 0, nullptr, h->dEdgeL, h->dEdgeR, h->dSlots, h->nEdges, P, h->dVals, h->dRhs);
+        h->nEdges, 0, nullptr, h->dEdgeL, h->dEdgeR, h->dSlots, h->nEdges, P, h->dVals, h->dRhs, h->dEdgeOwned);
     timer_end(h, NALU_GPU_T_ASSEMBLE_EDGES);
     NG_HIP(hipGetLastError());
     return NALU_GPU_OK;
@@ -615,7 +617,7 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
     if (n == 0) continue;
     k_assemble_edges<Op, false><<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(
         n, h->colorOff[c], h->dColorPerm, h->dEdgeL, h->dEdgeR, h->dSlots, h->nEdges, P, h->dVals,
-        h->dRhs);
+        h->dRhs, h->dEdgeOwned);
   }
   timer_end(h, NALU_GPU_T_ASSEMBLE_EDGES);
   NG_HIP(hipGetLastError());
@@ -767,8 +769,8 @@ extern "C" int nalu_gpu_assemble_scalar_mass_be(nalu_gpu_linsys *h, const double
   NG_FINALIZED(h);
   NG_REQUIRE(qN && qNp1 && rhoN && rhoNp1 && vol && dt != 0.0, NALU_GPU_EINVAL, "bad mass-term input");
   NG_TRY(materialize_zero(h));
-  if (h->nSlices)
-    k_mass_be<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), qN, qNp1, rhoN, rhoNp1, vol, dt, h->dRhs);
+  if (h->nSlicesOwned)
+    k_mass_be<<<h->nSlicesOwned, SELL_C, 0, h->stream>>>(sell_view(h), qN, qNp1, rhoN, rhoNp1, vol, dt, h->dRhs);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
 }
@@ -797,8 +799,8 @@ extern "C" int nalu_gpu_nodal_grad_edges(nalu_gpu_linsys *h, nalu_gpu_vec3 area,
 {
   NG_FINALIZED(h);
   NG_REQUIRE(vec3_ok(area) && vol && q && gx && gy && gz, NALU_GPU_EINVAL, "nodal grad: null pointer");
-  if (h->nSlices)
-    k_nodal_grad<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), area, vol, q, gx, gy, gz);
+  if (h->nSlicesOwned)
+    k_nodal_grad<<<h->nSlicesOwned, SELL_C, 0, h->stream>>>(sell_view(h), area, vol, q, gx, gy, gz);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
 }

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <numeric>
 #include <thread>
+#include <unordered_map>
 
 #include "internal.hpp"
 
@@ -167,7 +168,8 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dV); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   NG_FREE(h->dY); NG_FREE(h->dList); NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf);
-  NG_FREE(h->dRecvBuf);
+  NG_FREE(h->dRecvBuf); NG_FREE(h->dEdgeOwned); NG_FREE(h->dExpSendRow); NG_FREE(h->dExpRecvRow);
+  NG_FREE(h->dExpRecvPos); NG_FREE(h->dExpSend); NG_FREE(h->dExpRecv);
   if (h->hPinned) (void)hipHostFree(h->hPinned);
   if (h->ownStream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -175,6 +177,28 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
 }
 
 // -------------------------------------------------------------- graph construction
+extern "C" int nalu_gpu_set_assembly_mode(nalu_gpu_linsys *h, int mode)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  NG_REQUIRE(h->state == 0, NALU_GPU_ESTATE, "set_assembly_mode comes before begin_construction");
+  NG_REQUIRE(mode == NALU_GPU_ASSEMBLY_OWNER_COMPUTES || mode == NALU_GPU_ASSEMBLY_EXPORT_SHARED_ROWS,
+             NALU_GPU_EINVAL, "unknown assembly mode %d", mode);
+  h->asmMode = mode;
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_set_edge_ownership(nalu_gpu_linsys *h, int64_t n_edges, const unsigned char *owned)
+{
+  NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
+  NG_REQUIRE(h->state == 1, NALU_GPU_ESTATE, "set_edge_ownership comes between the graph builders and finalize");
+  NG_REQUIRE(h->asmMode == NALU_GPU_ASSEMBLY_EXPORT_SHARED_ROWS, NALU_GPU_ESTATE,
+             "edge ownership only matters in export mode (nalu_gpu_set_assembly_mode)");
+  NG_REQUIRE(n_edges == h->nEdges && (owned || n_edges == 0), NALU_GPU_EINVAL,
+             "edge ownership for %lld edges, the graph has %lld", (long long)n_edges, (long long)h->nEdges);
+  h->edgeOwnedHost.assign(owned, owned + n_edges);
+  return NALU_GPU_OK;
+}
+
 extern "C" int nalu_gpu_begin_construction(nalu_gpu_linsys *h, int n_owned, int n_shared,
                                            int n_ghost, const int64_t *gids,
                                            const int *owner_ranks, int my_rank)
@@ -212,6 +236,7 @@ extern "C" int nalu_gpu_begin_construction(nalu_gpu_linsys *h, int n_owned, int 
   h->nShared = n_shared;
   h->nGhost = n_ghost;
   h->nCols = (int)n;
+  h->nRowsAll = n_owned + (h->asmMode == NALU_GPU_ASSEMBLY_EXPORT_SHARED_ROWS ? n_shared : 0);
   h->myRank = my_rank;
   h->gids.assign(gids, gids + n);
   if (owner_ranks) h->owners.assign(owner_ranks, owner_ranks + n);
@@ -481,7 +506,9 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
   NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
   NG_REQUIRE(h->state == 1, NALU_GPU_ESTATE, "finalize needs a system under construction");
   NG_DEVICE(h->device);
-  const int nO = h->nOwned;
+  // rows stored: the owned ones and, in export mode, the shared-not-owned ones behind them
+  // (row == local node id for both); everything below that says nO means "stored rows"
+  const int nO = h->nRowsAll;
 
   // addConnections + insert_graph_connections (src/TpetraLinearSystem.C:355-371,877-917):
   // the pattern of owned row a is {a} U {b : a and b share an entity}, columns ascending
@@ -522,8 +549,8 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
   });
   h->rowPtr.assign((size_t)nO + 1, 0);
   for (int i = 0; i < nO; ++i) h->rowPtr[i + 1] = h->rowPtr[i] + len[i];
-  h->nnz = h->rowPtr[nO];
-  h->colIdx.resize((size_t)h->nnz);
+  h->nnz = h->rowPtr[h->nOwned];  // of the owned matrix (the views the callers get)
+  h->colIdx.resize((size_t)h->rowPtr[nO]);
   parallel_for(nO, [&](int64_t r0, int64_t r1) {
     for (int64_t i = r0; i < r1; ++i)
       std::copy(&scratch[cnt[i]], &scratch[cnt[i]] + len[i], &h->colIdx[h->rowPtr[i]]);
@@ -532,6 +559,7 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
 
   // SELL slices
   h->nSlices = (nO + SELL_C - 1) / SELL_C;
+  h->nSlicesOwned = (h->nOwned + SELL_C - 1) / SELL_C;
   h->hSliceOff.assign((size_t)h->nSlices + 1, 0);
   h->hSliceWidth.assign((size_t)std::max(h->nSlices, 1), 0);
   for (int s = 0; s < h->nSlices; ++s) {
@@ -559,10 +587,10 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
     long long *dRowPtr = nullptr;
     int *dColIdx = nullptr;
     NG_HIP(hipMalloc(&dRowPtr, sizeof(long long) * ((size_t)nO + 1)));
-    NG_HIP(hipMalloc(&dColIdx, sizeof(int) * (size_t)std::max<int64_t>(h->nnz, 1)));
+    NG_HIP(hipMalloc(&dColIdx, sizeof(int) * (size_t)std::max<int64_t>(h->rowPtr[nO], 1)));
     NG_HIP(hipMemcpyAsync(dRowPtr, h->rowPtr.data(), sizeof(long long) * ((size_t)nO + 1),
                           hipMemcpyHostToDevice, h->stream));
-    NG_HIP(hipMemcpyAsync(dColIdx, h->colIdx.data(), sizeof(int) * (size_t)h->nnz,
+    NG_HIP(hipMemcpyAsync(dColIdx, h->colIdx.data(), sizeof(int) * (size_t)h->rowPtr[nO],
                           hipMemcpyHostToDevice, h->stream));
     if (h->nSlices > 0)
       k_csr_to_sell<<<h->nSlices, SELL_C, 0, h->stream>>>(nO, dRowPtr, dColIdx, h->dSliceOff,
@@ -648,6 +676,11 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
     NG_HIP(hipMalloc(&h->dEdgeR, sizeof(int) * (size_t)h->nEdges));
     NG_HIP(hipMemcpy(h->dEdgeL, eL.data(), sizeof(int) * (size_t)h->nEdges, hipMemcpyHostToDevice));
     NG_HIP(hipMemcpy(h->dEdgeR, eR.data(), sizeof(int) * (size_t)h->nEdges, hipMemcpyHostToDevice));
+    if (h->asmMode == NALU_GPU_ASSEMBLY_EXPORT_SHARED_ROWS) {
+      if (h->edgeOwnedHost.empty()) h->edgeOwnedHost.assign((size_t)h->nEdges, 1);
+      NG_HIP(hipMalloc(&h->dEdgeOwned, (size_t)h->nEdges));
+      NG_HIP(hipMemcpy(h->dEdgeOwned, h->edgeOwnedHost.data(), (size_t)h->nEdges, hipMemcpyHostToDevice));
+    }
     int *dErr = nullptr;
     NG_HIP(hipMalloc(&dErr, 2 * sizeof(int)));
     NG_HIP(hipMemsetAsync(dErr, 0, 2 * sizeof(int), h->stream));
@@ -708,27 +741,28 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
   // slices whose rows read shared/ghost columns ("boundary") and the rest ("interior"): the
   // SpMV of the interior slices overlaps the halo exchange (Tpetra's Import in apply)
   h->nInterior = h->nBoundary = 0;
-  if (h->nCols > nO && h->nSlices > 0) {
-    std::vector<char> halo((size_t)h->nSlices, 0);
-    parallel_for(h->nSlices, [&](int64_t a, int64_t b) {
+  if (h->nCols > h->nOwned && h->nSlicesOwned > 0) {
+    const int nOw = h->nOwned, nSo = h->nSlicesOwned;
+    std::vector<char> halo((size_t)nSo, 0);
+    parallel_for(nSo, [&](int64_t a, int64_t b) {
       for (int64_t sl = a; sl < b; ++sl) {
-        const int r1 = std::min(nO, (int)(sl + 1) * SELL_C);
+        const int r1 = std::min(nOw, (int)(sl + 1) * SELL_C);
         char any = 0;
         for (int64_t k = h->rowPtr[sl * SELL_C]; k < h->rowPtr[r1] && !any; ++k)
-          any = h->colIdx[k] >= nO;
+          any = h->colIdx[k] >= nOw;
         halo[sl] = any;
       }
     });
-    std::vector<int> lists((size_t)h->nSlices);
+    std::vector<int> lists((size_t)nSo);
     int ni = 0;
-    for (int sl = 0; sl < h->nSlices; ++sl)
+    for (int sl = 0; sl < nSo; ++sl)
       if (!halo[sl]) lists[ni++] = sl;
     h->nInterior = ni;
-    for (int sl = 0; sl < h->nSlices; ++sl)
+    for (int sl = 0; sl < nSo; ++sl)
       if (halo[sl]) lists[ni++] = sl;
-    h->nBoundary = h->nSlices - h->nInterior;
-    NG_HIP(hipMalloc(&h->dSliceLists, sizeof(int) * (size_t)h->nSlices));
-    NG_HIP(hipMemcpy(h->dSliceLists, lists.data(), sizeof(int) * (size_t)h->nSlices, hipMemcpyHostToDevice));
+    h->nBoundary = nSo - h->nInterior;
+    NG_HIP(hipMalloc(&h->dSliceLists, sizeof(int) * (size_t)nSo));
+    NG_HIP(hipMemcpy(h->dSliceLists, lists.data(), sizeof(int) * (size_t)nSo, hipMemcpyHostToDevice));
   }
   NG_HIP(hipMalloc(&h->dReduce, sizeof(double) * (REDUCE_CAP + 8)));  // + 8 ints of error counters
   NG_HIP(hipMalloc(&h->dScal, sizeof(SolverScalars)));
@@ -759,8 +793,8 @@ extern "C" int nalu_gpu_get_sizes(nalu_gpu_linsys *h, int64_t *n_rows, int64_t *
 extern "C" int nalu_gpu_get_graph(nalu_gpu_linsys *h, int64_t *row_ptr, int *col_idx)
 {
   NG_FINALIZED(h);
-  if (row_ptr) std::copy(h->rowPtr.begin(), h->rowPtr.end(), row_ptr);
-  if (col_idx) std::copy(h->colIdx.begin(), h->colIdx.end(), col_idx);
+  if (row_ptr) std::copy(h->rowPtr.begin(), h->rowPtr.begin() + h->nOwned + 1, row_ptr);
+  if (col_idx) std::copy(h->colIdx.begin(), h->colIdx.begin() + h->nnz, col_idx);
   return NALU_GPU_OK;
 }
 
@@ -894,7 +928,7 @@ int nalu_gpu::materialize_zero(nalu_gpu_linsys *h)
   if (!h->lazyZero) return NALU_GPU_OK;
   timer_begin(h, NALU_GPU_T_ZERO);
   NG_HIP(hipMemsetAsync(h->dVals, 0, sizeof(double) * (size_t)std::max<long long>(h->sellSize, 1), h->stream));
-  NG_HIP(hipMemsetAsync(h->dRhs, 0, sizeof(double) * (size_t)std::max(h->nOwned, 1), h->stream));
+  NG_HIP(hipMemsetAsync(h->dRhs, 0, sizeof(double) * (size_t)std::max(h->nRowsAll, 1), h->stream));
   timer_end(h, NALU_GPU_T_ZERO);
   h->lazyZero = false;
   return NALU_GPU_OK;
@@ -932,7 +966,16 @@ extern "C" int nalu_gpu_sum_into(nalu_gpu_linsys *h, int n_obj, const int *node_
   a.nPos = a.nRhs = 0;
   for (int i = 0; i < n_obj; ++i) {
     const int row = node_lids[i];
-    if (row >= h->nOwned) continue;
+    if (row >= h->nRowsAll) {
+      // :1495-1505: a shared-not-owned row goes to the shared matrix (export mode: handled like an
+      // owned row, it is stored); rows of ghosts are dropped silently there and here.  In
+      // owner-computes mode the shared rows do not exist: refusing beats losing the contribution.
+      NG_REQUIRE(row >= h->nOwned + h->nShared, NALU_GPU_EUNSUPPORTED,
+                 "sum_into: local node %d is shared-not-owned; in owner-computes mode its row is assembled by its "
+                 "owner (pass the entity there), or use NALU_GPU_ASSEMBLY_EXPORT_SHARED_ROWS "
+                 "(src/TpetraLinearSystem.C:1495-1505, 1686-1707)", row);
+      continue;
+    }
     const int64_t b = h->rowPtr[row], e = h->rowPtr[row + 1];
     const long long off = h->hSliceOff[row / SELL_C];
     // sum_into_row (:1363-1383) passes once through the row with the columns in ascending
@@ -981,13 +1024,17 @@ int nalu_gpu::ensure_list(nalu_gpu_linsys *h, int64_t n, const int *lids)
 }
 
 // applyDirichletBCs / resetRows (src/TpetraLinearSystem.C:1546-1583, 1650-1683)
-__global__ void k_replace_rows(SellView A, int n, const int *lids, double diagVal,
+__global__ void k_replace_rows(SellView A, int nOwned, int n, const int *lids, double diagVal,
                                const double *solution, const double *bc, double *rhs)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const int row = lids[t];
   if (row >= A.nRows) return;  // shared copy: its row lives (and is replaced) on the owner
+  // export mode stores the shared copy: all zero, diagonal included, rhs 0 (:1565-1580), so that
+  // the export adds nothing to the owner's replaced row
+  const bool sharedCopy = row >= nOwned;
+  if (sharedCopy) diagVal = 0.0;
   const int slice = row / SELL_C, r = row % SELL_C;
   const long long off = A.sliceOff[slice];
   const int w = A.sliceWidth[slice];
@@ -995,7 +1042,7 @@ __global__ void k_replace_rows(SellView A, int n, const int *lids, double diagVa
     const long long pos = off + (long long)k * SELL_C + r;
     A.vals[pos] = (A.tags[pos] == TAG_DIAG) ? diagVal : 0.0;
   }
-  rhs[row] = bc ? (bc[row] - solution[row]) : 0.0;
+  rhs[row] = (bc && !sharedCopy) ? (bc[row] - solution[row]) : 0.0;
 }
 
 static int replace_rows(nalu_gpu_linsys *h, int64_t n, const int *lids, double diagVal,
@@ -1009,8 +1056,8 @@ static int replace_rows(nalu_gpu_linsys *h, int64_t n, const int *lids, double d
   if (n == 0) return NALU_GPU_OK;
   NG_TRY(ensure_list(h, n, lids));
   timer_begin(h, NALU_GPU_T_BC);
-  k_replace_rows<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(sell_view(h), (int)n, h->dList,
-                                                                     diagVal, sol, bc, h->dRhs);
+  k_replace_rows<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(sell_view_all(h), h->nOwned, (int)n,
+                                                                     h->dList, diagVal, sol, bc, h->dRhs);
   timer_end(h, NALU_GPU_T_BC);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
@@ -1033,10 +1080,202 @@ extern "C" int nalu_gpu_reset_rows(nalu_gpu_linsys *h, int64_t n, const int *lid
 extern "C" int nalu_gpu_load_complete(nalu_gpu_linsys *h)
 {
   NG_FINALIZED(h);
-  // src/TpetraLinearSystem.C:1699,1706 export shared-not-owned rows to their owner.  Here
-  // every owned row was assembled completely by its owner (cut edges are duplicated on
-  // both sides), so there is nothing to move; only pending zeros are made real.
-  return materialize_zero(h);
+  // src/TpetraLinearSystem.C:1699,1706 export shared-not-owned rows to their owner.  In
+  // owner-computes mode every owned row was assembled completely by its owner (cut edges are
+  // duplicated on both sides), so there is nothing to move; only pending zeros are made real.
+  NG_TRY(materialize_zero(h));
+  if (h->asmMode == NALU_GPU_ASSEMBLY_EXPORT_SHARED_ROWS) return export_shared_rows(h);
+  return NALU_GPU_OK;
+}
+
+// ------------------------------------------------ export of the shared-not-owned rows
+// Tpetra's doExport(sharedNotOwned -> owned, ADD) for matrix and rhs (src/TpetraLinearSystem.C:
+// 1699, 1706).  A value message carries, per shared row, [rhs, v_0 .. v_{W-1}] (W = the sender's
+// longest shared row, entries in the sender's column order).  The plan -- which owned row and which
+// matrix slot every received number is added to -- is built once from a set-up exchange of the
+// rows' global ids (as doubles: ids below 2^53 are exact), so the hot part is pack -> exchange ->
+// add, one launch per neighbour in neighbour order: a fixed summation order.
+namespace {
+
+__global__ void k_export_pack(int n, const int *__restrict__ rows, int W, SellView A,
+                              const double *__restrict__ rhs, double *__restrict__ out)
+{
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int row = rows[q];
+  const int slice = row / SELL_C, r = row % SELL_C;
+  const long long off = A.sliceOff[slice];
+  const int w = A.sliceWidth[slice];
+  double *o = out + (size_t)q * (W + 1);
+  o[0] = rhs[row];
+  for (int k = 0; k < W; ++k) o[1 + k] = k < w ? A.vals[off + (long long)k * SELL_C + r] : 0.0;
+}
+
+__global__ void k_export_add(int n, int W, const double *__restrict__ in, const int *__restrict__ rowOf,
+                             const long long *__restrict__ pos, double *vals, double *rhs)
+{
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const double *m = in + (size_t)q * (W + 1);
+  rhs[rowOf[q]] += m[0];
+  for (int k = 0; k < W; ++k) {
+    const long long p = pos[(size_t)q * W + k];
+    if (p >= 0) vals[p] += m[1 + k];
+  }
+}
+
+// one neighbour exchange of host data through the comm's exchange_rows (set-up only)
+int exchange_host(nalu_gpu_linsys *h, const std::vector<double> &send, const std::vector<int64_t> &so,
+                  std::vector<double> &recv, const std::vector<int64_t> &ro)
+{
+  double *dS = nullptr, *dR = nullptr;
+  NG_HIP(hipMalloc(&dS, sizeof(double) * std::max<size_t>(send.size(), 1)));
+  NG_HIP(hipMalloc(&dR, sizeof(double) * std::max<size_t>(recv.size(), 1)));
+  if (!send.empty())
+    NG_HIP(hipMemcpyAsync(dS, send.data(), sizeof(double) * send.size(), hipMemcpyHostToDevice, h->stream));
+  NG_HIP(hipStreamSynchronize(h->stream));
+  const int rc = h->comm.exchange_rows(h->comm.ctx, dS, so.data(), dR, ro.data(), h->stream);
+  if (rc == 0 && !recv.empty())
+    (void)hipMemcpyAsync(recv.data(), dR, sizeof(double) * recv.size(), hipMemcpyDeviceToHost, h->stream);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(dS);
+  (void)hipFree(dR);
+  NG_REQUIRE(rc == 0, NALU_GPU_EHIP, "exchange_rows callback failed: %s", callback_error());
+  return NALU_GPU_OK;
+}
+
+int ensure_export_plan(nalu_gpu_linsys *h)
+{
+  if (h->exportReady) return NALU_GPU_OK;
+  NG_REQUIRE(h->hasComm && h->comm.exchange_rows, NALU_GPU_ESTATE,
+             "export mode needs a comm with exchange_rows (nalu_gpu_set_comm) and the halo plan");
+  NG_REQUIRE(h->recvCount == h->nCols - h->nOwned, NALU_GPU_ESTATE, "export mode: set the halo plan first");
+  const int nN = h->nNbr, nO = h->nOwned;
+  // shared rows by owner, in neighbour order (ascending local id = ascending global id inside)
+  std::vector<std::vector<int>> rowsTo((size_t)nN);
+  int Wloc = 0;
+  for (int s = 0; s < h->nShared; ++s) {
+    const int lid = nO + s;
+    int p = 0;
+    while (p < nN && h->nbrRanks[p] != h->owners[lid]) ++p;
+    NG_REQUIRE(p < nN, NALU_GPU_EINVAL, "shared node %d is owned by rank %d, which is no halo neighbour", lid,
+               h->owners[lid]);
+    rowsTo[p].push_back(lid);
+    Wloc = std::max(Wloc, (int)(h->rowPtr[lid + 1] - h->rowPtr[lid]));
+  }
+  // 1. how many rows of which width come from whom
+  std::vector<double> cs((size_t)2 * nN), cr((size_t)2 * nN);
+  std::vector<int64_t> two((size_t)nN + 1);
+  for (int p = 0; p <= nN; ++p) two[p] = 2 * p;
+  for (int p = 0; p < nN; ++p) { cs[2 * p] = (double)rowsTo[p].size(); cs[2 * p + 1] = (double)Wloc; }
+  NG_TRY(exchange_host(h, cs, two, cr, two));
+  h->expSendRows.assign(nN, 0); h->expRecvRows.assign(nN, 0);
+  h->expSendW.assign(nN, Wloc); h->expRecvW.assign(nN, 0);
+  std::vector<int64_t> mso((size_t)nN + 1, 0), mro((size_t)nN + 1, 0);
+  h->expSendOff.assign((size_t)nN + 1, 0); h->expRecvOff.assign((size_t)nN + 1, 0);
+  h->expRecvPosOff.assign((size_t)nN + 1, 0);
+  for (int p = 0; p < nN; ++p) {
+    h->expSendRows[p] = (int)rowsTo[p].size();
+    h->expRecvRows[p] = (int)cr[2 * p];
+    h->expRecvW[p] = (int)cr[2 * p + 1];
+    mso[p + 1] = mso[p] + (int64_t)h->expSendRows[p] * (Wloc + 2);
+    mro[p + 1] = mro[p] + (int64_t)h->expRecvRows[p] * (h->expRecvW[p] + 2);
+    h->expSendOff[p + 1] = h->expSendOff[p] + (int64_t)h->expSendRows[p] * (Wloc + 1);
+    h->expRecvOff[p + 1] = h->expRecvOff[p] + (int64_t)h->expRecvRows[p] * (h->expRecvW[p] + 1);
+    h->expRecvPosOff[p + 1] = h->expRecvPosOff[p] + (int64_t)h->expRecvRows[p] * h->expRecvW[p];
+  }
+  // 2. the rows' global ids: [row gid, length, column gids ..., -1 padding]
+  std::vector<double> ms((size_t)mso[nN], -1.0), mr((size_t)mro[nN], -1.0);
+  std::vector<int> sendRow;
+  for (int p = 0; p < nN; ++p)
+    for (size_t q = 0; q < rowsTo[p].size(); ++q) {
+      const int lid = rowsTo[p][q];
+      sendRow.push_back(lid);
+      double *m = &ms[(size_t)mso[p] + q * (Wloc + 2)];
+      const int64_t b = h->rowPtr[lid], len = h->rowPtr[lid + 1] - b;
+      m[0] = (double)h->gids[lid];
+      m[1] = (double)len;
+      for (int64_t k = 0; k < len; ++k) m[2 + k] = (double)h->gids[h->colIdx[b + k]];
+    }
+  NG_TRY(exchange_host(h, ms, mso, mr, mro));
+  // 3. where every received number goes
+  std::unordered_map<int64_t, int> lidOf;
+  lidOf.reserve((size_t)h->nCols * 2);
+  for (int i = 0; i < h->nCols; ++i) lidOf[h->gids[i]] = i;
+  std::vector<int> recvRow;
+  std::vector<long long> recvPos((size_t)h->expRecvPosOff[nN], -1);
+  long long missing = 0;
+  for (int p = 0; p < nN; ++p) {
+    const int W = h->expRecvW[p];
+    for (int q = 0; q < h->expRecvRows[p]; ++q) {
+      const double *m = &mr[(size_t)mro[p] + (size_t)q * (W + 2)];
+      auto it = lidOf.find((int64_t)m[0]);
+      NG_REQUIRE(it != lidOf.end() && it->second < nO, NALU_GPU_EINVAL,
+                 "export: rank %d sent a row of global id %lld, which this rank does not own", h->nbrRanks[p],
+                 (long long)m[0]);
+      const int row = it->second;
+      recvRow.push_back(row);
+      const int *cb = &h->colIdx[h->rowPtr[row]], *ce = &h->colIdx[h->rowPtr[row + 1]];
+      const long long off = h->hSliceOff[row / SELL_C];
+      for (int k = 0; k < (int)m[1]; ++k) {
+        auto ic = lidOf.find((int64_t)m[2 + k]);
+        const int *f = ic == lidOf.end() ? ce : std::lower_bound(cb, ce, ic->second);
+        if (f == ce || *f != ic->second) { ++missing; continue; }
+        recvPos[(size_t)h->expRecvPosOff[p] + (size_t)q * W + k] = off + (long long)(f - cb) * SELL_C + row % SELL_C;
+      }
+    }
+  }
+  NG_REQUIRE(missing == 0, NALU_GPU_EINVAL,
+             "export: %lld entries of received rows have no slot in the owner's graph: pass every edge that "
+             "touches an owned node to the graph builders (the reference exchanges graph rows at finalize)",
+             missing);
+  NG_FREE(h->dExpSendRow); NG_FREE(h->dExpRecvRow); NG_FREE(h->dExpRecvPos); NG_FREE(h->dExpSend); NG_FREE(h->dExpRecv);
+  NG_HIP(hipMalloc(&h->dExpSendRow, sizeof(int) * std::max<size_t>(sendRow.size(), 1)));
+  NG_HIP(hipMalloc(&h->dExpRecvRow, sizeof(int) * std::max<size_t>(recvRow.size(), 1)));
+  NG_HIP(hipMalloc(&h->dExpRecvPos, sizeof(long long) * std::max<size_t>(recvPos.size(), 1)));
+  NG_HIP(hipMalloc(&h->dExpSend, sizeof(double) * (size_t)std::max<int64_t>(h->expSendOff[nN], 1)));
+  NG_HIP(hipMalloc(&h->dExpRecv, sizeof(double) * (size_t)std::max<int64_t>(h->expRecvOff[nN], 1)));
+  if (!sendRow.empty())
+    NG_HIP(hipMemcpy(h->dExpSendRow, sendRow.data(), sizeof(int) * sendRow.size(), hipMemcpyHostToDevice));
+  if (!recvRow.empty())
+    NG_HIP(hipMemcpy(h->dExpRecvRow, recvRow.data(), sizeof(int) * recvRow.size(), hipMemcpyHostToDevice));
+  if (!recvPos.empty())
+    NG_HIP(hipMemcpy(h->dExpRecvPos, recvPos.data(), sizeof(long long) * recvPos.size(), hipMemcpyHostToDevice));
+  h->exportReady = true;
+  return NALU_GPU_OK;
+}
+
+}  // namespace
+
+int nalu_gpu::export_shared_rows(nalu_gpu_linsys *h)
+{
+  if (h->nCols == h->nOwned && h->nNbr == 0) return NALU_GPU_OK;  // one rank: nothing is shared
+  NG_TRY(ensure_export_plan(h));
+  const int nN = h->nNbr;
+  const SellView A = sell_view_all(h);
+  int rowBase = 0;
+  for (int p = 0; p < nN; ++p) {
+    const int n = h->expSendRows[p];
+    if (n)
+      k_export_pack<<<(n + 255) / 256, 256, 0, h->stream>>>(n, h->dExpSendRow + rowBase, h->expSendW[p], A, h->dRhs,
+                                                            h->dExpSend + h->expSendOff[p]);
+    rowBase += n;
+  }
+  NG_HIP(hipGetLastError());
+  NG_REQUIRE(h->comm.exchange_rows(h->comm.ctx, h->dExpSend, h->expSendOff.data(), h->dExpRecv,
+                                   h->expRecvOff.data(), h->stream) == 0,
+             NALU_GPU_EHIP, "exchange_rows callback failed: %s", callback_error());
+  rowBase = 0;
+  for (int p = 0; p < nN; ++p) {  // neighbour order: a fixed summation order
+    const int n = h->expRecvRows[p];
+    if (n)
+      k_export_add<<<(n + 255) / 256, 256, 0, h->stream>>>(n, h->expRecvW[p], h->dExpRecv + h->expRecvOff[p],
+                                                           h->dExpRecvRow + rowBase,
+                                                           h->dExpRecvPos + h->expRecvPosOff[p], h->dVals, h->dRhs);
+    rowBase += n;
+  }
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
 }
 
 // ---------------------------------------------------------- edge slots and colours
@@ -1069,7 +1308,7 @@ int nalu_gpu::ensure_edge_slots(nalu_gpu_linsys *h)
              "edge-parallel scatter modes need < 2^31 matrix slots");
   NG_HIP(hipMalloc(&h->dSlots, sizeof(int) * 4 * (size_t)h->nEdges));
   const long long nb = (h->nEdges + 255) / 256;
-  k_edge_slots<<<(unsigned)nb, 256, 0, h->stream>>>(h->nEdges, h->dEdgeL, h->dEdgeR, h->nOwned,
+  k_edge_slots<<<(unsigned)nb, 256, 0, h->stream>>>(h->nEdges, h->dEdgeL, h->dEdgeR, h->nRowsAll,
                                                      h->dSliceOff, h->dSliceWidth, h->dCols,
                                                      h->dSlots);
   NG_HIP(hipGetLastError());
@@ -1165,6 +1404,7 @@ extern "C" int nalu_gpu_set_comm(nalu_gpu_linsys *h, const nalu_gpu_comm *comm)
              "all three callbacks are required");
   h->comm = *comm;
   h->hasComm = true;
+  h->exportReady = false;  // (the plan's set-up exchange runs through the new comm)
   return NALU_GPU_OK;
 }
 

@@ -48,6 +48,9 @@ struct SellView {
   // position i < 8 is (ordWord >> 3 i) & 7, bit 24 + i says that a smaller entry follows later
   // ("early": its diagonal / rhs shares wait in a stash so that they are added in CSR order)
   const unsigned *ordWord;
+  // export mode only (else null): edgeOwned[e] == 0 marks an edge another rank assembles; the
+  // assembly kernels treat its entries as plain graph entries
+  const unsigned char *edgeOwned;
   int nSlices;
   int nRows;
 };
@@ -103,6 +106,24 @@ struct nalu_gpu_linsys {
   int numDof = 1;
   int state = 0;  // 0 created, 1 under construction, 2 finalized
   int nOwned = 0, nShared = 0, nGhost = 0, nCols = 0, myRank = 0;
+  // NALU_GPU_ASSEMBLY_EXPORT_SHARED_ROWS: the matrix also stores the rows of the shared-not-owned
+  // nodes (rows nOwned .. nOwned + nShared: the reference's sharedNotOwnedMatrix_), assembled from
+  // the locally owned edges and added to their owners' rows by loadComplete
+  int asmMode = 0;
+  int nRowsAll = 0;       // rows stored: nOwned (+ nShared in export mode)
+  int nSlicesOwned = 0;   // slices that hold owned rows (what the solver kernels sweep)
+  std::vector<unsigned char> edgeOwnedHost;
+  unsigned char *dEdgeOwned = nullptr;
+  // export plan (built on the first loadComplete of export mode)
+  bool exportReady = false;
+  std::vector<int64_t> expSendOff, expRecvOff;  // per neighbour, in doubles (value messages)
+  std::vector<int> expSendRows, expRecvRows;    // rows per neighbour
+  std::vector<int> expSendW, expRecvW;          // message width (entries per row) per neighbour
+  int *dExpSendRow = nullptr;                   // shared rows in send order
+  int *dExpRecvRow = nullptr;                   // owned row of every received row
+  long long *dExpRecvPos = nullptr;             // SELL position of every received entry (-1: padding)
+  std::vector<int64_t> expRecvPosOff;           // per neighbour offsets into dExpRecvPos
+  double *dExpSend = nullptr, *dExpRecv = nullptr;
   std::vector<int64_t> gids;
   std::vector<int> owners;
   std::vector<EntBlock> blocks;
@@ -270,8 +291,18 @@ inline SellView sell_view(const nalu_gpu_linsys *h)
   v.tMul = h->dTMul;
   v.exMaskT = h->dExMaskT;
   v.ordWord = h->dOrdWord;
-  v.nSlices = h->nSlices;
+  v.edgeOwned = h->dEdgeOwned;
+  v.nSlices = h->nSlicesOwned;  // the solver's view: owned rows only
   v.nRows = h->nOwned;
+  return v;
+}
+
+// the assembly's view: every stored row (owned, and in export mode the shared-not-owned ones)
+inline SellView sell_view_all(const nalu_gpu_linsys *h)
+{
+  SellView v = sell_view(h);
+  v.nSlices = h->nSlices;
+  v.nRows = h->nRowsAll;
   return v;
 }
 
@@ -304,6 +335,7 @@ int ensure_list(nalu_gpu_linsys *h, int64_t n, const int *lids);
 int halo_exchange(nalu_gpu_linsys *h, double *vec);
 int halo_begin(nalu_gpu_linsys *h, const double *vec);
 int halo_end(nalu_gpu_linsys *h, double *vec);
+int export_shared_rows(nalu_gpu_linsys *h);
 // reductions: kernels leave per-block partials in dPartials[slot][block]; this sums them
 // in a fixed order into dReduce[0..nslots) and (if a comm is set) all-reduces them.
 int finish_reduction(nalu_gpu_linsys *h, int nslots, int nblocks, const double *src = nullptr);

@@ -153,8 +153,8 @@ extern "C" int nalu_gpu_scatter_plan_create(nalu_gpu_linsys *h, int64_t n_ent, i
   p->nEnt = n_ent;
   p->nObj = n_obj;
   p->lids.assign(ent_lids, ent_lids + tot);
-  const int nO = h->nOwned;
-  // rows beyond the owned ones are assembled by their owner (see nalu_gpu_sum_into)
+  const int nO = h->nRowsAll;  // rows stored (export mode: the shared-not-owned copies too)
+  // rows beyond the stored ones are assembled by their owner (see nalu_gpu_sum_into)
   std::vector<int> rowOf((size_t)std::max<int64_t>(tot, 1));
   std::vector<short> kIdx((size_t)std::max<int64_t>(tot * n_obj, 1));
   std::atomic<bool> tooWide(false);
@@ -277,7 +277,7 @@ extern "C" int nalu_gpu_sum_into_batch(nalu_gpu_linsys *h, nalu_gpu_scatter_plan
   const long long nThreads = (long long)p->nEnt * p->nObj;
   if (scatter_mode == NALU_GPU_SCATTER_ROWS) {
     timer_begin(h, NALU_GPU_T_ASSEMBLE_EDGES);
-    k_batch_rows<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), p->nObj, p->dIncPtr, p->dInc,
+    k_batch_rows<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view_all(h), p->nObj, p->dIncPtr, p->dInc,
                                                        p->dK, lhs_dev, rhs_dev, h->dRhs);
     timer_end(h, NALU_GPU_T_ASSEMBLE_EDGES);
   } else if (scatter_mode == NALU_GPU_SCATTER_ATOMIC) {

@@ -289,8 +289,8 @@ template <bool DOT, bool DINV>
 int launch_spmv(nalu_gpu_linsys *h, const double *x, double *y, bool useDone, int *nblocks,
                 const int *list = nullptr, int nList = 0)
 {
-  if (nblocks) *nblocks = h->nSlices;
-  const int nb = list ? nList : h->nSlices;
+  if (nblocks) *nblocks = h->nSlicesOwned;
+  const int nb = list ? nList : h->nSlicesOwned;
   if (nb == 0) return NALU_GPU_OK;
   timer_begin(h, NALU_GPU_T_SPMV);
   k_spmv<DOT, DINV><<<nb, SELL_C, 0, h->stream>>>(sell_view(h), x, h->dDinv, y, h->dSlicePartials,
@@ -1380,7 +1380,7 @@ extern "C" int nalu_gpu_check_system(nalu_gpu_linsys *h, nalu_gpu_check_info *in
   NG_TRY(materialize_zero(h));
   int *dOut = (int *)(h->dReduce + REDUCE_CAP);
   NG_HIP(hipMemsetAsync(dOut, 0, 8 * sizeof(int), h->stream));
-  if (h->nSlices) k_check_rows<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view(h), h->dRhs, dOut);
+  if (h->nSlicesOwned) k_check_rows<<<h->nSlicesOwned, SELL_C, 0, h->stream>>>(sell_view(h), h->dRhs, dOut);
   NG_HIP(hipGetLastError());
   int *o = (int *)((char *)h->hPinned + 3072);
   NG_HIP(hipMemcpyAsync(o, dOut, 6 * sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -125,6 +125,14 @@ class GpuLinearSystem:
         except Exception:
             pass
 
+    def set_assembly_mode(self, mode):
+        """"owner_computes" (default) or "export" (the reference's shared-not-owned rows + Export ADD)"""
+        L.check(self.lib.nalu_gpu_set_assembly_mode(self.h, {"owner_computes": 0, "export": 1}[mode]))
+
+    def set_edge_ownership(self, locally_owned):
+        a = _np(locally_owned, np.uint8)
+        L.check(self.lib.nalu_gpu_set_edge_ownership(self.h, len(a), a.ctypes.data))
+
     # ---- graph ----------------------------------------------------------------
     def beginLinearSystemConstruction(self, n_owned, n_shared=0, n_ghost=0, gids=None,
                                       owners=None, my_rank=0):

@@ -50,6 +50,15 @@ def test_comm_on_a_non_default_stream(nproc, backend):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_export_mode_matches_owner_computes_and_np2_gold(nproc):
+    """Reference-style assembly (each edge on one rank, shared-not-owned rows exported with ADD by
+    loadComplete) gives the owner-computes rows to 1e-12, the np = 1 oracle rows, the same GMRES
+    history, and the np = 2 gold matrix of unit_tests/UnitTestTpetra.C through the host sumInto."""
+    _launch(nproc, "export")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("method,side_stream", [("cg", False), ("gmres", True)])
 def test_native_rccl_callbacks_world_1(method, side_stream):
     """libnalu_gpu_rccl.so (include/nalu_gpu_rccl.h): unique id -> ncclCommInitRank -> callbacks

@@ -57,11 +57,24 @@ def test_tpetra_basic_gold_through_c_abi(G, oracle):
     g1.finalizeLinearSystem()
     assert np.diff(g0.graph()[0]).tolist() == [8, 8, 8, 8, 12, 12, 12, 12]
     assert np.diff(g1.graph()[0]).tolist() == [8, 8, 8, 8]
+    import torch
+    blk = torch.as_tensor(np.asarray(ELEM_VALS, dtype=np.float64).reshape(1, 8, 8), device="cuda:0").contiguous()
     for gg, elems, gid_of in ((g0, [0, 1], list(range(1, 13))), (g1, [1], [9, 10, 11, 12, 5, 6, 7, 8])):
         gg.zeroSystem()
         lid = {gid: i for i, gid in enumerate(gid_of)}
         for e in elems:
-            gg.sumInto([lid[n + 1] for n in m.hex_nodes[e]], np.zeros(8), ELEM_VALS)
+            lids = [lid[n + 1] for n in m.hex_nodes[e]]
+            if any(l >= gg.n_owned for l in lids) and gg is g1:
+                # owner-computes mode stores no shared-not-owned rows: the host sumInto refuses the
+                # entity instead of dropping the rows of nodes 5-8 (they are rank 0's to assemble);
+                # the bulk path is the documented way to pass cut entities on both sides
+                with pytest.raises(G.NaluGpuError, match="shared-not-owned"):
+                    gg.sumInto(lids, np.zeros(8), ELEM_VALS)
+                plan = gg.createScatterPlan([lids])
+                gg.sumIntoBatch(plan, torch.zeros(1, 8, dtype=torch.float64, device="cuda:0"), blk)
+                plan.close()
+            else:
+                gg.sumInto(lids, np.zeros(8), ELEM_VALS)
         gg.loadComplete()
         rp, ci = gg.graph()
         v = gg.matrix_values()
