@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_prereduce(const double *__restrict__ sr
 int prereduce_slices(nalu_gpu_linsys *h, int *count, const double **src, bool useDone)
 {
   *src = h->dSlicePartials;
-  if (*count <= 4096) return NALU_GPU_OK;
+  if (*count <= 16384) return NALU_GPU_OK;  // one 1024-thread workgroup sums these in ~1 us
   double *dst = h->dSlicePartials + h->nSlices;
   k_prereduce<<<PRE_WG, 256, 0, h->stream>>>(h->dSlicePartials, *count, dst, useDone ? h->dScal : nullptr);
   NG_HIP(hipGetLastError());
@@ -568,14 +568,28 @@ __global__ void k_cg_scal_a(SolverScalars *sc, const double *red) { cg_scal_a(sc
 
 // r -= alpha q with the partial sums of r.r and r.z; the x update waits for k_cg_p, which
 // reads p anyway (one vector read less per iteration)
-__global__ __launch_bounds__(256) void k_cg_update(long long n, const SolverScalars *__restrict__ sc,
+// red != nullptr (multi-rank): alpha = rz / (p.Ap) is formed here from the all-reduced dot product
+// by every thread, and recorded by one -- the one-thread scalar kernel between the all-reduce and
+// this kernel (one more dependent launch per iteration) is folded away.  sc->rz is not written
+// by this kernel, so every workgroup reads the same operands.
+__global__ __launch_bounds__(256) void k_cg_update(long long n, SolverScalars *__restrict__ sc,
                                                     const double *__restrict__ dinv,
                                                     const double *__restrict__ q,
                                                     double *__restrict__ r,
-                                                    double *__restrict__ partials)
+                                                    double *__restrict__ partials,
+                                                    const double *__restrict__ red)
 {
   if (sc->done) return;
-  const double alpha = sc->alpha;
+  double alpha;
+  if (red) {
+    alpha = sc->rz / red[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      sc->alpha = alpha;
+      if (sc->alphaHist && sc->iter < sc->histCap) sc->alphaHist[sc->iter] = alpha;
+    }
+  } else {
+    alpha = sc->alpha;
+  }
   double acc[2] = {0.0, 0.0};
   GRID_STRIDE(i, n) {
     // streamed operands are loaded nontemporally: they do not displace the vector the next
@@ -1019,13 +1033,15 @@ int solve_cg(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEve
     NG_TRY((spmv_with_halo<true, false>(h, slot(it), h->dQ, true, &sb)));
     const double *pp = nullptr;
     NG_TRY(prereduce_slices(h, &sb, &pp, true));
+    // multi-rank: the update kernel forms alpha itself from the all-reduced p.Ap in the reduce
+    // buffer (which the next reduction only overwrites after that kernel has finished)
     if (h->hasComm) {
       NG_TRY(finish_reduction(h, 1, sb, pp));
-      k_cg_scal_a<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
     } else {
       k_reduce_partials<EPI_CG_A><<<1, RED_T, 0, h->stream>>>(pp, sb, 1, h->dReduce, h->dScal, nullptr);
     }
-    k_cg_update<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dDinv, h->dQ, h->dR, h->dPartials);
+    k_cg_update<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dDinv, h->dQ, h->dR, h->dPartials,
+                                           h->hasComm ? h->dReduce : nullptr);
     if (h->hasComm) {
       NG_TRY(finish_reduction(h, 2, vb));
       k_cg_scal_b<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist);

@@ -9,6 +9,9 @@
 //   3  mode 0, two rows per thread (128-thread workgroups, rows t and t+128)
 //   4  mode 0 + 18 area-vector loads + 8 stores per row (the whole skeleton)
 //   5  mode 1 + area as double4 per (row, slot) [6 loads of 32 B] + 8 stores
+//   7  z-marching skeleton: a workgroup takes line y of planes z0 .. z0+Z-1 (Z = argv[2], default 8;
+//      the z neighbours are the thread's own previous / next rows, kept in registers): per step
+//      own line + y-/y+ lines (33 loads), 12 area loads, 8 stores.  XCD run length argv[3].
 //   6  mode 0 but neighbour lines staged through LDS by 16-byte loads (each thread loads 16 B
 //      = two rows of one field; reads its own row back from LDS)
 // Usage: gatherbench <mode> [occupancyLimiterLdsBytes]
@@ -164,6 +167,41 @@ __global__ __launch_bounds__(MODE == 3 ? 128 : 256) void k(Fields F, int nSlices
   if (acc == 1.2345e300) out[0] = acc;
 }
 
+__global__ __launch_bounds__(256) void kmarch(Fields F, int Z, int run, double *out, double *big)
+{
+  const int nTasks = 65536 / Z;
+  const int T = xcd_run(blockIdx.x, nTasks, run);
+  const int y = T & 255, zc = T >> 8;
+  const long long n = 65536LL * 256;
+  double acc = 0.0, prev[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) prev[i] = 0.0;
+  for (int st = 0; st < Z; ++st) {
+    const long long line = (long long)(zc * Z + st) * 256 + y;
+    const long long row = line * 256 + threadIdx.x;
+    double cur[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) cur[i] = F.f[i][row];
+    const long long ym = clampRow(row - 256, row, n), yp = clampRow(row + 256, row, n);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc += F.f[i][ym] + F.f[i][yp];
+    // area: x+ (own), y+ (own), y- (row - 256), z- (previous plane's z+); x- by shuffle, z+ next step
+    const long long ea[4] = {row, n + row, n + ym, 2 * n + clampRow(row - 65536, row, n)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc += F.area[c][ea[e]];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc += cur[i] * prev[i];
+    const long long base = line * 256 * 8 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) big[base + j * 256] = acc + j;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) prev[i] = cur[i];
+  }
+  if (acc == 1.2345e300) out[0] = acc;
+}
+
 template <int MODE>
 void run(Fields F, int nSlices, double *out, double *big, size_t lds)
 {
@@ -206,6 +244,22 @@ int main(int argc, char **argv)
   CK(hipMalloc(&out, 8));
   CK(hipMalloc(&big, n * 8 * 8));
   if (mode == 6 && lds < 22528) lds = 22528;
+  if (mode == 7) {
+    const int Z = argc > 2 ? atoi(argv[2]) : 8, run = argc > 3 ? atoi(argv[3]) : 8;
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+      CK(hipEventRecord(a));
+      kmarch<<<65536 / Z, 256>>>(F, Z, run, out, big);
+      CK(hipEventRecord(b));
+      CK(hipDeviceSynchronize());
+      float ms; CK(hipEventElapsedTime(&ms, a, b));
+      if (rep >= 2 && ms < best) best = ms;
+    }
+    printf("mode 7 Z %d run %d: %.3f ms\n", Z, run, best);
+    return 0;
+  }
   switch (mode) {
     case 0: run<0>(F, nSlices, out, big, lds); break;
     case 1: run<1>(F, nSlices, out, big, lds); break;
