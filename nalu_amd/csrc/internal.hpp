@@ -192,6 +192,14 @@ struct nalu_gpu_linsys {
   bool sgsReady = false;
   std::vector<int> sgsFwdOff, sgsBwdOff;
   int *dSgsFwdRows = nullptr, *dSgsBwdRows = nullptr;
+  // level-major copies of the strictly lower / upper triangle (precond.hip)
+  std::vector<long long> lmFwdEntOff, lmBwdEntOff;
+  std::vector<int> lmFwdW, lmBwdW;
+  long long lmFwdN = 0, lmBwdN = 0;
+  long long *dLmFwdSrc = nullptr, *dLmBwdSrc = nullptr;
+  int *dLmFwdCol = nullptr, *dLmBwdCol = nullptr, *dLmTpos = nullptr;
+  double *dLmFwdVal = nullptr, *dLmBwdVal = nullptr, *dLmDinvF = nullptr, *dLmDinvB = nullptr;
+  double *dLmR = nullptr, *dLmT = nullptr, *dLmZ = nullptr;
 
   // multicolour SGS (precond.hip): rows bucketed by greedy colour
   bool mcReady = false;
@@ -343,6 +351,7 @@ int vec_grid(int64_t n);
 void release_plan(nalu_gpu_scatter_plan *p);
 int ensure_sgs_levels(nalu_gpu_linsys *h);
 int apply_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone);
+int sgs_compute(nalu_gpu_linsys *h);
 int ensure_mc_colors(nalu_gpu_linsys *h);
 int apply_mc_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone);
 

@@ -11,7 +11,17 @@
 // construction for the backward sweep).  A multicolour ordering would be faster but is a
 // different preconditioner (different residual history); this one is the reference's.
 // Lattice 256^3: 766 levels of ~22k rows each way.
+//
+// Level-major storage.  The rows of a level are far apart in the SELL layout (255 rows on the
+// lattice), so sweeping them in place costs a 128-byte line per 8-byte value.  compute() (once
+// per solve) therefore gathers the strictly lower / strictly upper entries into level-major ELL
+// blocks -- level l holds cnt_l rows x w_l entries, entry-major, with the column stored as the
+// POSITION of that row in the same level order -- and apply() works on vectors permuted to that
+// order: r is gathered once, the level kernels stream contiguous values and read t / z of the
+// previous levels nearly contiguously, z is scattered back once.  Same operations in the same
+// order per row as before: bit-identical results.
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "internal.hpp"
@@ -62,6 +72,63 @@ __global__ __launch_bounds__(256) void k_sgs_backward(SellView A, const int *__r
     if (c > i && c < A.nRows) s += A.vals[pos] * z[c];
   }
   z[i] = t[i] - s * dinv[i];
+}
+
+// ---- level-major sweeps
+// values of the level-major blocks from the SELL matrix (compute(), once per solve)
+__global__ __launch_bounds__(256) void k_lm_gather_vals(long long n, const long long *__restrict__ src,
+                                                         const double *__restrict__ vals, double *__restrict__ out)
+{
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long p = src[i];
+  out[i] = p >= 0 ? vals[p] : 0.0;
+}
+
+// out[q] = v[rows[q]] (gather) or out[rows[q]] = v[q] (scatter)
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_lm_permute(int n, const int *__restrict__ rows, const int *__restrict__ done,
+                                                     const double *__restrict__ v, double *__restrict__ out)
+{
+  if (done && *done) return;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  if (SCATTER) out[rows[q]] = v[q];
+  else out[q] = v[rows[q]];
+}
+
+// one level of the forward sweep: t_q = (r_q - sum_k a_k t[col_k]) * dinv_q, k ascending (= column order)
+__global__ __launch_bounds__(256) void k_lm_forward(int cnt, int w, const double *__restrict__ av,
+                                                     const int *__restrict__ ac, const int *__restrict__ done,
+                                                     const double *__restrict__ rq, const double *__restrict__ dinvq,
+                                                     double *tq, int o)
+{
+  if (done && *done) return;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= cnt) return;
+  double s = rq[o + q];
+  for (int k = 0; k < w; ++k) {
+    const int c = ac[(size_t)k * cnt + q];
+    if (c >= 0) s -= av[(size_t)k * cnt + q] * tq[c];
+  }
+  tq[o + q] = s * dinvq[o + q];
+}
+
+// one level of the backward sweep: z_q = t - (sum_k a_k z[col_k]) * dinv_q
+__global__ __launch_bounds__(256) void k_lm_backward(int cnt, int w, const double *__restrict__ av,
+                                                      const int *__restrict__ ac, const int *__restrict__ done,
+                                                      const int *__restrict__ tpos, const double *__restrict__ tq,
+                                                      const double *__restrict__ dinvq, double *zq, int o)
+{
+  if (done && *done) return;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= cnt) return;
+  double s = 0.0;
+  for (int k = 0; k < w; ++k) {
+    const int c = ac[(size_t)k * cnt + q];
+    if (c >= 0) s += av[(size_t)k * cnt + q] * zq[c];
+  }
+  zq[o + q] = tq[tpos[o + q]] - s * dinvq[o + q];
 }
 
 // Multicolour SGS ("mt_sgs"): rows of one colour are not coupled, so a sweep is one launch per
@@ -139,31 +206,141 @@ int nalu_gpu::ensure_sgs_levels(nalu_gpu_linsys *h)
   bucket_by_level(lf, nf, rows, h->sgsFwdOff);
   NG_HIP(hipMalloc(&h->dSgsFwdRows, sizeof(int) * (size_t)std::max(n, 1)));
   NG_HIP(hipMemcpy(h->dSgsFwdRows, rows.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  std::vector<int> rowsF = rows;
   bucket_by_level(lb, nb, rows, h->sgsBwdOff);
   NG_HIP(hipMalloc(&h->dSgsBwdRows, sizeof(int) * (size_t)std::max(n, 1)));
   NG_HIP(hipMemcpy(h->dSgsBwdRows, rows.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  const std::vector<int> &rowsB = rows;
+
+  // level-major blocks (see the header comment)
+  std::vector<int> posF((size_t)n), posB((size_t)n);
+  for (int q = 0; q < n; ++q) { posF[rowsF[q]] = q; posB[rowsB[q]] = q; }
+  auto build = [&](bool fwd, const std::vector<int> &order, const std::vector<int> &off,
+                   const std::vector<int> &posOf, std::vector<long long> &entOff, std::vector<int> &width,
+                   std::vector<long long> &src, std::vector<int> &col) {
+    const int nl = (int)off.size() - 1;
+    entOff.assign((size_t)nl + 1, 0);
+    width.assign((size_t)std::max(nl, 1), 0);
+    for (int l = 0; l < nl; ++l) {
+      int w = 0;
+      for (int q = off[l]; q < off[l + 1]; ++q) {
+        const int i = order[q];
+        int c0 = 0;
+        for (int64_t k = h->rowPtr[i]; k < h->rowPtr[i + 1]; ++k) {
+          const int c = h->colIdx[k];
+          c0 += fwd ? (c < i) : (c > i && c < n);
+        }
+        w = std::max(w, c0);
+      }
+      width[l] = w;
+      entOff[l + 1] = entOff[l] + (long long)w * (off[l + 1] - off[l]);
+    }
+    src.assign((size_t)std::max<long long>(entOff[nl], 1), -1);
+    col.assign((size_t)std::max<long long>(entOff[nl], 1), -1);
+    for (int l = 0; l < nl; ++l) {
+      const int cnt = off[l + 1] - off[l];
+      for (int q = 0; q < cnt; ++q) {
+        const int i = order[off[l] + q];
+        const long long so = h->hSliceOff[i / SELL_C] + i % SELL_C;
+        int kk = 0;
+        for (int64_t k = h->rowPtr[i]; k < h->rowPtr[i + 1]; ++k) {
+          const int c = h->colIdx[k];
+          if (fwd ? (c < i) : (c > i && c < n)) {
+            const size_t idx = (size_t)entOff[l] + (size_t)kk * cnt + q;
+            src[idx] = so + (long long)(k - h->rowPtr[i]) * SELL_C;
+            col[idx] = posOf[c];
+            ++kk;
+          }
+        }
+      }
+    }
+  };
+  std::vector<long long> srcF, srcB;
+  std::vector<int> colF, colB, tposB((size_t)std::max(n, 1));
+  build(true, rowsF, h->sgsFwdOff, posF, h->lmFwdEntOff, h->lmFwdW, srcF, colF);
+  build(false, rowsB, h->sgsBwdOff, posB, h->lmBwdEntOff, h->lmBwdW, srcB, colB);
+  for (int q = 0; q < n; ++q) tposB[q] = posF[rowsB[q]];
+  auto up = [&](auto &vec, auto **dst) -> int {
+    using T = typename std::remove_reference<decltype(vec[0])>::type;
+    NG_HIP(hipMalloc(dst, sizeof(T) * vec.size()));
+    NG_HIP(hipMemcpy(*dst, vec.data(), sizeof(T) * vec.size(), hipMemcpyHostToDevice));
+    return NALU_GPU_OK;
+  };
+  NG_TRY(up(srcF, &h->dLmFwdSrc)); NG_TRY(up(colF, &h->dLmFwdCol));
+  NG_TRY(up(srcB, &h->dLmBwdSrc)); NG_TRY(up(colB, &h->dLmBwdCol));
+  NG_TRY(up(tposB, &h->dLmTpos));
+  h->lmFwdN = (long long)srcF.size();
+  h->lmBwdN = (long long)srcB.size();
+  NG_HIP(hipMalloc(&h->dLmFwdVal, sizeof(double) * srcF.size()));
+  NG_HIP(hipMalloc(&h->dLmBwdVal, sizeof(double) * srcB.size()));
+  const size_t nv = sizeof(double) * (size_t)std::max(n, 1);
+  NG_HIP(hipMalloc(&h->dLmDinvF, nv)); NG_HIP(hipMalloc(&h->dLmDinvB, nv));
+  NG_HIP(hipMalloc(&h->dLmR, nv)); NG_HIP(hipMalloc(&h->dLmT, nv)); NG_HIP(hipMalloc(&h->dLmZ, nv));
   h->sgsReady = true;
   return NALU_GPU_OK;
 }
 
-// z = SGS(r) on the owned rows; uses h->dT as the intermediate vector.  r and z may alias
-// neither each other nor dT.
+// Ifpack2 compute() for SGS: refresh the level-major copies of the matrix values and of dinv
+// (the matrix changes between solves, the level structure does not).  dDinv must be ready.
+int nalu_gpu::sgs_compute(nalu_gpu_linsys *h)
+{
+  NG_TRY(ensure_sgs_levels(h));
+  const int n = h->nOwned;
+  if (n == 0) return NALU_GPU_OK;
+  k_lm_gather_vals<<<(unsigned)((h->lmFwdN + 255) / 256), 256, 0, h->stream>>>(h->lmFwdN, h->dLmFwdSrc, h->dVals,
+                                                                                h->dLmFwdVal);
+  k_lm_gather_vals<<<(unsigned)((h->lmBwdN + 255) / 256), 256, 0, h->stream>>>(h->lmBwdN, h->dLmBwdSrc, h->dVals,
+                                                                                h->dLmBwdVal);
+  k_lm_permute<false><<<(n + 255) / 256, 256, 0, h->stream>>>(n, h->dSgsFwdRows, nullptr, h->dDinv, h->dLmDinvF);
+  k_lm_permute<false><<<(n + 255) / 256, 256, 0, h->stream>>>(n, h->dSgsBwdRows, nullptr, h->dDinv, h->dLmDinvB);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+// z = SGS(r) on the owned rows (level-major sweeps; sgs_compute must have run for the current
+// matrix).  r and z may alias each other.  NG_SGS_INPLACE=1 selects the first implementation (the
+// sweeps on the SELL matrix itself, 5x slower at 256^3), kept as the cross-check of the tests.
 int nalu_gpu::apply_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone)
 {
   NG_TRY(ensure_sgs_levels(h));
-  const SellView A = sell_view(h);
-  const SolverScalars *sc = useDone ? h->dScal : nullptr;
   const int nf = (int)h->sgsFwdOff.size() - 1, nb = (int)h->sgsBwdOff.size() - 1;
+  static const bool inplace = getenv("NG_SGS_INPLACE") && atoi(getenv("NG_SGS_INPLACE")) != 0;
+  if (inplace) {
+    const SellView A = sell_view(h);
+    const SolverScalars *sc = useDone ? h->dScal : nullptr;
+    for (int l = 0; l < nf; ++l) {
+      const int o = h->sgsFwdOff[l], cnt = h->sgsFwdOff[l + 1] - o;
+      k_sgs_forward<<<(cnt + 255) / 256, 256, 0, h->stream>>>(A, h->dSgsFwdRows + o, cnt, sc, h->dDinv, r,
+                                                              h->dT);
+    }
+    for (int l = 0; l < nb; ++l) {
+      const int o = h->sgsBwdOff[l], cnt = h->sgsBwdOff[l + 1] - o;
+      k_sgs_backward<<<(cnt + 255) / 256, 256, 0, h->stream>>>(A, h->dSgsBwdRows + o, cnt, sc, h->dDinv,
+                                                               h->dT, z);
+    }
+    NG_HIP(hipGetLastError());
+    return NALU_GPU_OK;
+  }
+  const int n = h->nOwned;
+  if (n == 0) return NALU_GPU_OK;
+  const int *done = useDone ? &h->dScal->done : nullptr;
+  // ~2 x (number of levels) dependent launches (1532 at 256^3), each a kernel boundary plus two
+  // dependent memory round trips (column positions -> t values): ~6 us per level, latency-bound.
+  // (Replaying them from a HIP graph was measured and changes nothing: the time is on the device.)
+  k_lm_permute<false><<<(n + 255) / 256, 256, 0, h->stream>>>(n, h->dSgsFwdRows, done, r, h->dLmR);
   for (int l = 0; l < nf; ++l) {
     const int o = h->sgsFwdOff[l], cnt = h->sgsFwdOff[l + 1] - o;
-    k_sgs_forward<<<(cnt + 255) / 256, 256, 0, h->stream>>>(A, h->dSgsFwdRows + o, cnt, sc, h->dDinv, r,
-                                                            h->dT);
+    k_lm_forward<<<(cnt + 255) / 256, 256, 0, h->stream>>>(cnt, h->lmFwdW[l], h->dLmFwdVal + h->lmFwdEntOff[l],
+                                                           h->dLmFwdCol + h->lmFwdEntOff[l], done, h->dLmR,
+                                                           h->dLmDinvF, h->dLmT, o);
   }
   for (int l = 0; l < nb; ++l) {
     const int o = h->sgsBwdOff[l], cnt = h->sgsBwdOff[l + 1] - o;
-    k_sgs_backward<<<(cnt + 255) / 256, 256, 0, h->stream>>>(A, h->dSgsBwdRows + o, cnt, sc, h->dDinv,
-                                                             h->dT, z);
+    k_lm_backward<<<(cnt + 255) / 256, 256, 0, h->stream>>>(cnt, h->lmBwdW[l], h->dLmBwdVal + h->lmBwdEntOff[l],
+                                                            h->dLmBwdCol + h->lmBwdEntOff[l], done, h->dLmTpos,
+                                                            h->dLmT, h->dLmDinvB, h->dLmZ, o);
   }
+  k_lm_permute<true><<<(n + 255) / 256, 256, 0, h->stream>>>(n, h->dSgsBwdRows, done, h->dLmZ, z);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
 }

@@ -1458,6 +1458,7 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
   if (cfg->precond == NALU_GPU_PRECOND_MT_SGS) NG_TRY(ensure_mc_colors(h));
   NG_HIP(hipGetLastError());
   NG_TRY(halo_exchange(h, h->dDinv));
+  if (cfg->precond == NALU_GPU_PRECOND_SGS) NG_TRY(sgs_compute(h));
   if (cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV) NG_TRY(cheb_compute(h));
   timer_end(h, NALU_GPU_T_PRECOND);
   {
