@@ -104,7 +104,9 @@ public:
     nalu_gpu_solver_config c;
     if (method_ == "cg") c.method = NALU_GPU_METHOD_CG;
     else if (method_ == "gmres") c.method = NALU_GPU_METHOD_GMRES;
-    else throw std::runtime_error("solver method '" + method_ + "' not supported on the GPU (cg, gmres)");
+    else if (method_ == "biCgStab" || method_ == "bicgstab") c.method = NALU_GPU_METHOD_BICGSTAB;
+    else if (method_ == "tfqmr") c.method = NALU_GPU_METHOD_TFQMR;
+    else throw std::runtime_error("solver method '" + method_ + "' not supported on the GPU (cg, gmres, biCgStab, tfqmr)");
     if (precond_ == "jacobi" || precond_ == "default") c.precond = NALU_GPU_PRECOND_JACOBI;
     else if (precond_ == "sgs") c.precond = NALU_GPU_PRECOND_SGS;
     else if (precond_ == "mt_sgs") c.precond = NALU_GPU_PRECOND_MT_SGS;

@@ -40,7 +40,8 @@ enum {
   NALU_GPU_SCATTER_ATOMIC = 2   /* edge-parallel, fp64 atomics on diag/rhs: NOT bit-reproducible */
 };
 
-enum { NALU_GPU_METHOD_CG = 0, NALU_GPU_METHOD_GMRES = 1 };
+/* Belos solver names of src/LinearSolverConfig.C:34-55 as the regression inputs use them */
+enum { NALU_GPU_METHOD_CG = 0, NALU_GPU_METHOD_GMRES = 1, NALU_GPU_METHOD_BICGSTAB = 2, NALU_GPU_METHOD_TFQMR = 3 };
 enum { NALU_GPU_PRECOND_NONE = 0, NALU_GPU_PRECOND_JACOBI = 1, NALU_GPU_PRECOND_SGS = 2,
        NALU_GPU_PRECOND_CHEBYSHEV = 3,
        NALU_GPU_PRECOND_MT_SGS = 4 /* "mt_sgs" (src/LinearSolverConfig.C:76-80): multicolour SGS */ };

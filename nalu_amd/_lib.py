@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NALU_GPU_LIB", os.path.join(_HERE, "libnalu_gpu.so"))
 
 SCATTER = {"rows": 0, "colored": 1, "atomic": 2}
-METHOD = {"cg": 0, "gmres": 1}
+METHOD = {"cg": 0, "gmres": 1, "biCgStab": 2, "bicgstab": 2, "tfqmr": 3}
 PRECOND = {"none": 0, "jacobi": 1, "default": 1, "sgs": 2, "chebyshev": 3, "mt_sgs": 4}
 PECLET = {"classic": 0, "tanh": 1}
 # DofStatus (include/TpetraLinearSystem.h:49-55)

@@ -170,6 +170,8 @@ struct nalu_gpu_linsys {
   // solver workspace
   double *dR = nullptr, *dP = nullptr, *dQ = nullptr, *dW = nullptr, *dT = nullptr;
   double *dV = nullptr;  // GMRES basis, (kspace+1) x nCols
+  double *dKry = nullptr;  // work vectors of BiCGStab / TFQMR, kryCount x nCols
+  int kryCount = 0;
   int vCap = 0;
   double *dPartials = nullptr;  // PARTIAL_SLOTS x MAX_BLOCKS
   double *dSlicePartials = nullptr;  // nSlices (+64): per-slice partials of the SpMV-fused dot

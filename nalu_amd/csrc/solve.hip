@@ -1301,8 +1301,232 @@ int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int check
   return NALU_GPU_OK;
 }
 
-}  // namespace
+// ------------------------------------------------------------ BiCGStab / TFQMR
+// The two other Belos methods the regression inputs name (biCgStab: 1 input, tfqmr: 3, e.g.
+// reg_tests/test_files/edgeHybridFluids/edgeHybridFluids.i:10).  Right-preconditioned like the
+// rest (src/LinearSolver.C:105); Belos' iteration classes are Trilinos code, so the published
+// algorithms are restated (van der Vorst; Freund's TFQMR as in Saad, Alg. 7.8): parity
+// unpinned.  They are the seldom-used methods: the scalar recurrences run on the host (one
+// small device-to-host copy per dot product), the vector work in the kernels below.
 
+// out = a x + b y + c z (null y / z are skipped; out may alias any of them)
+__global__ __launch_bounds__(256) void k_lin3(long long n, double a, const double *x, double b, const double *y,
+                                               double c, const double *z, double *out)
+{
+  GRID_STRIDE(i, n) {
+    double v = a * x[i];
+    if (y) v = v + b * y[i];
+    if (z) v = v + c * z[i];
+    out[i] = v;
+  }
+}
+
+// p = r + beta (p - omega v)
+__global__ __launch_bounds__(256) void k_bicg_p(long long n, double beta, double omega, const double *r,
+                                                 const double *v, double *p)
+{
+  GRID_STRIDE(i, n) p[i] = r[i] + beta * (p[i] - omega * v[i]);
+}
+
+// v = beta (au + beta v)
+__global__ __launch_bounds__(256) void k_tfqmr_v(long long n, double beta, const double *au, double *v)
+{
+  GRID_STRIDE(i, n) v[i] = beta * (au[i] + beta * v[i]);
+}
+
+__global__ __launch_bounds__(256) void k_scale_by(long long n, const double *dinv, const double *r, double *z)
+{
+  GRID_STRIDE(i, n) z[i] = dinv[i] * r[i];
+}
+
+struct HostKrylov {
+  nalu_gpu_linsys *h;
+  long long n;
+  int vb, precond;
+  int dots(int k, const double *const *a, const double *const *b, double *out)
+  {
+    for (int i = 0; i < k; ++i)
+      k_dot<<<vb, 256, 0, h->stream>>>(n, a[i], b[i], h->dPartials + (size_t)i * MAX_BLOCKS);
+    NG_HIP(hipGetLastError());
+    NG_TRY(finish_reduction(h, k, vb));
+    double *pin = (double *)((char *)h->hPinned + 2048);
+    NG_HIP(hipMemcpyAsync(pin, h->dReduce, sizeof(double) * k, hipMemcpyDeviceToHost, h->stream));
+    NG_HIP(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < k; ++i) out[i] = pin[i];
+    return NALU_GPU_OK;
+  }
+  int dot1(const double *a, const double *b, double *out) { return dots(1, &a, &b, out); }
+  // z = M^-1 r (z is a column-space vector: it is multiplied by A next)
+  int prec(const double *r, double *z)
+  {
+    if (precond == NALU_GPU_PRECOND_NONE || precond == NALU_GPU_PRECOND_JACOBI) {
+      k_scale_by<<<vb, 256, 0, h->stream>>>(n, h->dDinv, r, z);  // (dinv = 1 without a preconditioner)
+      NG_HIP(hipGetLastError());
+      return NALU_GPU_OK;
+    }
+    return apply_general(h, precond, r, z, false);
+  }
+  int amul(double *x, double *y)
+  {
+    int sb = 0;
+    return spmv_with_halo<false, false>(h, x, y, false, &sb);
+  }
+  void lin3(double a, const double *x, double b, const double *y, double c, const double *z, double *out)
+  {
+    k_lin3<<<vb, 256, 0, h->stream>>>(n, a, x, b, y, c, z, out);
+  }
+};
+
+int ensure_kry(nalu_gpu_linsys *h, int count)
+{
+  if (h->kryCount >= count) return NALU_GPU_OK;
+  NG_HIP(hipStreamSynchronize(h->stream));
+  if (h->dKry) (void)hipFree(h->dKry);
+  h->dKry = nullptr;
+  const size_t ld = (size_t)std::max(h->nCols, 1);
+  NG_HIP(hipMalloc(&h->dKry, sizeof(double) * ld * (size_t)count));
+  NG_HIP(hipMemsetAsync(h->dKry, 0, sizeof(double) * ld * (size_t)count, h->stream));
+  h->kryCount = count;
+  return NALU_GPU_OK;
+}
+
+// iteration count / history go through the device scalars like the other methods' (read back by
+// nalu_gpu_solve)
+__global__ void k_host_scal_store(SolverScalars *sc, int iter, int histCap)
+{
+  sc->iter = iter;
+  sc->done = 1;
+  sc->histCap = histCap;
+}
+
+int store_host_history(nalu_gpu_linsys *h, const std::vector<double> &hist, int iters)
+{
+  const int nh = std::min((int)hist.size(), h->histCap);
+  NG_HIP(hipMemcpyAsync(h->dHist, hist.data(), sizeof(double) * nh, hipMemcpyHostToDevice, h->stream));
+  k_host_scal_store<<<1, 1, 0, h->stream>>>(h->dScal, iters, h->histCap);
+  NG_HIP(hipStreamSynchronize(h->stream));  // hist is a host temporary
+  return NALU_GPU_OK;
+}
+
+int solve_bicgstab(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg)
+{
+  const long long n = h->nOwned;
+  const size_t ld = (size_t)std::max(h->nCols, 1);
+  NG_TRY(ensure_kry(h, 8));
+  HostKrylov K{h, n, vec_grid(n), cfg->precond};
+  double *r = h->dKry, *rh = r + ld, *p = rh + ld, *v = p + ld, *sv = v + ld, *t = sv + ld, *y = t + ld, *z = y + ld;
+  double *x = h->dX;
+  const size_t bytes = sizeof(double) * (size_t)n;
+  NG_HIP(hipMemsetAsync(x, 0, sizeof(double) * ld, h->stream));
+  NG_HIP(hipMemcpyAsync(r, h->dRhs, bytes, hipMemcpyDeviceToDevice, h->stream));
+  NG_HIP(hipMemcpyAsync(rh, h->dRhs, bytes, hipMemcpyDeviceToDevice, h->stream));
+  NG_HIP(hipMemsetAsync(p, 0, bytes, h->stream));
+  NG_HIP(hipMemsetAsync(v, 0, bytes, h->stream));
+  std::vector<double> hist(1, 1.0);
+  double rr0 = 0.0;
+  NG_TRY(K.dot1(r, r, &rr0));
+  const double r0 = std::sqrt(rr0);
+  int iters = 0;
+  double rhoOld = 1.0, alpha = 1.0, omega = 1.0;
+  while (r0 != 0.0 && iters < cfg->max_iterations) {
+    double rhoNew = 0.0, rhv = 0.0, d2[2] = {0.0, 0.0}, rr = 0.0;
+    NG_TRY(K.dot1(rh, r, &rhoNew));
+    const double beta = (rhoNew / rhoOld) * (alpha / omega);
+    k_bicg_p<<<K.vb, 256, 0, h->stream>>>(n, beta, omega, r, v, p);
+    NG_TRY(K.prec(p, y));
+    NG_TRY(K.amul(y, v));
+    NG_TRY(K.dot1(rh, v, &rhv));
+    alpha = rhoNew / rhv;
+    K.lin3(1.0, r, -alpha, v, 0.0, nullptr, sv);  // s = r - alpha v
+    NG_TRY(K.prec(sv, z));
+    NG_TRY(K.amul(z, t));
+    const double *a2[2] = {t, t}, *b2[2] = {sv, t};
+    NG_TRY(K.dots(2, a2, b2, d2));
+    omega = d2[0] / d2[1];
+    K.lin3(1.0, x, alpha, y, omega, z, x);         // x = x + alpha y + omega z
+    K.lin3(1.0, sv, -omega, t, 0.0, nullptr, r);  // r = s - omega t
+    rhoOld = rhoNew;
+    ++iters;
+    NG_TRY(K.dot1(r, r, &rr));
+    const double rel = std::sqrt(rr) / r0;
+    hist.push_back(rel);
+    if (rel <= cfg->tolerance) break;
+  }
+  return store_host_history(h, hist, iters);
+}
+
+int solve_tfqmr(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg)
+{
+  const long long n = h->nOwned;
+  const size_t ld = (size_t)std::max(h->nCols, 1);
+  NG_TRY(ensure_kry(h, 8));
+  HostKrylov K{h, n, vec_grid(n), cfg->precond};
+  double *w = h->dKry, *u = w + ld, *v = u + ld, *d = v + ld, *au = d + ld, *rs = au + ld, *ys = rs + ld, *z = ys + ld;
+  double *x = h->dX;
+  const size_t bytes = sizeof(double) * (size_t)n;
+  NG_HIP(hipMemsetAsync(x, 0, sizeof(double) * ld, h->stream));
+  NG_HIP(hipMemcpyAsync(w, h->dRhs, bytes, hipMemcpyDeviceToDevice, h->stream));
+  NG_HIP(hipMemcpyAsync(u, h->dRhs, bytes, hipMemcpyDeviceToDevice, h->stream));
+  NG_HIP(hipMemcpyAsync(rs, h->dRhs, bytes, hipMemcpyDeviceToDevice, h->stream));
+  NG_HIP(hipMemsetAsync(d, 0, bytes, h->stream));
+  NG_HIP(hipMemsetAsync(ys, 0, bytes, h->stream));
+  std::vector<double> hist(1, 1.0);
+  double rho = 0.0;
+  NG_TRY(K.dot1(rs, w, &rho));
+  const double r0 = std::sqrt(rho);
+  int iters = 0;
+  if (r0 != 0.0) {
+    NG_TRY(K.prec(u, z));
+    NG_TRY(K.amul(z, v));  // v = A M^-1 u
+    NG_HIP(hipMemcpyAsync(au, v, bytes, hipMemcpyDeviceToDevice, h->stream));
+  }
+  double tau = r0, theta = 0.0, eta = 0.0, alpha = 0.0;
+  while (r0 != 0.0 && iters < cfg->max_iterations) {
+    for (int half = 0; half < 2; ++half) {
+      if (half == 0) {
+        double vr = 0.0;
+        NG_TRY(K.dot1(v, rs, &vr));
+        alpha = rho / vr;
+      } else {
+        K.lin3(1.0, u, -alpha, v, 0.0, nullptr, u);
+        NG_TRY(K.prec(u, z));
+        NG_TRY(K.amul(z, au));
+      }
+      K.lin3(1.0, w, -alpha, au, 0.0, nullptr, w);
+      const double dfac = theta * theta * eta / alpha;
+      K.lin3(1.0, u, dfac, d, 0.0, nullptr, d);
+      double ww = 0.0;
+      NG_TRY(K.dot1(w, w, &ww));
+      theta = std::sqrt(ww) / tau;
+      const double c = 1.0 / std::sqrt(1.0 + theta * theta);
+      tau = tau * theta * c;
+      eta = c * c * alpha;
+      K.lin3(1.0, ys, eta, d, 0.0, nullptr, ys);
+      if (half == 1) {
+        double rhoNew = 0.0;
+        NG_TRY(K.dot1(rs, w, &rhoNew));
+        const double beta = rhoNew / rho;
+        rho = rhoNew;
+        K.lin3(1.0, w, beta, u, 0.0, nullptr, u);
+        k_tfqmr_v<<<K.vb, 256, 0, h->stream>>>(n, beta, au, v);
+        NG_TRY(K.prec(u, z));
+        NG_TRY(K.amul(z, au));
+        K.lin3(1.0, au, 1.0, v, 0.0, nullptr, v);
+      }
+    }
+    ++iters;
+    const double rel = std::sqrt(2.0 * iters + 1.0) * tau / r0;
+    hist.push_back(rel);
+    if (rel <= cfg->tolerance) break;
+  }
+  if (r0 != 0.0) {
+    NG_TRY(K.prec(ys, z));
+    NG_HIP(hipMemcpyAsync(x, z, bytes, hipMemcpyDeviceToDevice, h->stream));
+  }
+  return store_host_history(h, hist, iters);
+}
+
+}  // namespace
 
 extern "C" int nalu_gpu_spmv(nalu_gpu_linsys *h, const double *x_dev, double *y_dev)
 {
@@ -1422,8 +1646,9 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
 {
   NG_FINALIZED(h);
   NG_REQUIRE(cfg && info, NALU_GPU_EINVAL, "null config/info");
-  NG_REQUIRE(cfg->method == NALU_GPU_METHOD_CG || cfg->method == NALU_GPU_METHOD_GMRES,
-             NALU_GPU_EUNSUPPORTED, "solver method %d (supported: cg, gmres)", cfg->method);
+  NG_REQUIRE(cfg->method == NALU_GPU_METHOD_CG || cfg->method == NALU_GPU_METHOD_GMRES ||
+                 cfg->method == NALU_GPU_METHOD_BICGSTAB || cfg->method == NALU_GPU_METHOD_TFQMR,
+             NALU_GPU_EUNSUPPORTED, "solver method %d (supported: cg, gmres, biCgStab, tfqmr)", cfg->method);
   NG_REQUIRE(cfg->precond == NALU_GPU_PRECOND_NONE || cfg->precond == NALU_GPU_PRECOND_JACOBI ||
                  cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV ||
                  cfg->precond == NALU_GPU_PRECOND_MT_SGS,
@@ -1479,7 +1704,9 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
   const auto t1 = std::chrono::steady_clock::now();
 
   timer_begin(h, NALU_GPU_T_SOLVE);
-  if (cfg->method == NALU_GPU_METHOD_CG &&
+  if (cfg->method == NALU_GPU_METHOD_BICGSTAB) NG_TRY(solve_bicgstab(h, cfg));
+  else if (cfg->method == NALU_GPU_METHOD_TFQMR) NG_TRY(solve_tfqmr(h, cfg));
+  else if (cfg->method == NALU_GPU_METHOD_CG &&
       (cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV ||
        cfg->precond == NALU_GPU_PRECOND_MT_SGS))
     NG_TRY(solve_cg_general(h, cfg, checkEvery));

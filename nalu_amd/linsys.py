@@ -55,7 +55,7 @@ class LinearSolverConfig:
 
     def c_struct(self, is_final_outer_iter=False):
         if self.method not in L.METHOD:
-            raise L.NaluGpuError(f"solver method '{self.method}' not supported (cg, gmres)")
+            raise L.NaluGpuError(f"solver method '{self.method}' not supported (cg, gmres, biCgStab, tfqmr)")
         if self.preconditioner not in L.PRECOND:
             raise L.NaluGpuError(f"preconditioner '{self.preconditioner}' not supported on GPU")
         tol = self.final_tolerance if is_final_outer_iter else self.tolerance

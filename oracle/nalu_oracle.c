@@ -1303,6 +1303,92 @@ int orc_solve(orc_linsys *ls, const orc_solver_config *cfg, double *finalResidNr
       for (int64_t i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
     }
     free(r); free(z); free(p); free(q);
+  } else if (cfg->method == 2) {
+    /* right-preconditioned BiCGStab (Belos "BICGSTAB", the method name biCgStab of 1 regression
+     * input, e.g. reg_tests/test_files/dgNonConformal; Belos::BiCGStabIter is Trilinos code, not
+     * in the tree: van der Vorst's algorithm restated, PARITY UNPINNED).  One iteration = two
+     * operator applications; the status test sees the recurrence residual r. */
+    double *r = (double *)malloc(sizeof(double) * (size_t)n), *rh = (double *)malloc(sizeof(double) * (size_t)n);
+    double *p = (double *)calloc((size_t)n, sizeof(double)), *v = (double *)calloc((size_t)n, sizeof(double));
+    double *sv = (double *)malloc(sizeof(double) * (size_t)n), *t = (double *)malloc(sizeof(double) * (size_t)n);
+    double *y = (double *)malloc(sizeof(double) * (size_t)n), *z = (double *)malloc(sizeof(double) * (size_t)n);
+    memcpy(r, b, sizeof(double) * (size_t)n);
+    memcpy(rh, b, sizeof(double) * (size_t)n);
+    double rho_old = 1.0, alpha = 1.0, omega = 1.0;
+    while (iters < cfg->max_iterations) {
+      const double rho_new = dot(rh, r, n);
+      const double beta = (rho_new / rho_old) * (alpha / omega);
+      for (int64_t i = 0; i < n; ++i) p[i] = r[i] + beta * (p[i] - omega * v[i]);
+      apply_precond(ls, cfg->precond, dinv, p, y, tmp);
+      orc_spmv(ls, y, v);
+      alpha = rho_new / dot(rh, v, n);
+      for (int64_t i = 0; i < n; ++i) sv[i] = r[i] - alpha * v[i];
+      apply_precond(ls, cfg->precond, dinv, sv, z, tmp);
+      orc_spmv(ls, z, t);
+      omega = dot(t, sv, n) / dot(t, t, n);
+      for (int64_t i = 0; i < n; ++i) x[i] = x[i] + alpha * y[i] + omega * z[i];
+      for (int64_t i = 0; i < n; ++i) r[i] = sv[i] - omega * t[i];
+      rho_old = rho_new;
+      ++iters;
+      const double rel = orc_norm2(r, n) / r0;
+      if (history && hl < history_cap) history[hl++] = rel;
+      if (rel <= cfg->tolerance) break;
+    }
+    free(r); free(rh); free(p); free(v); free(sv); free(t); free(y); free(z);
+  } else if (cfg->method == 3) {
+    /* right-preconditioned TFQMR (Belos "TFQMR", method name tfqmr of 3 regression inputs, e.g.
+     * reg_tests/test_files/edgeHybridFluids/edgeHybridFluids.i:10; Belos::TFQMRIter is Trilinos
+     * code: Freund's algorithm as in Saad, Iterative Methods, Alg. 7.8, on the operator A M^-1
+     * with x = M^-1 (sum eta d) applied once at the end; one iteration = the even and the odd
+     * half step; the status test sees the bound sqrt(2 iter + 1) tau.  PARITY UNPINNED). */
+    double *w = (double *)malloc(sizeof(double) * (size_t)n), *u = (double *)malloc(sizeof(double) * (size_t)n);
+    double *v = (double *)malloc(sizeof(double) * (size_t)n), *d = (double *)calloc((size_t)n, sizeof(double));
+    double *au = (double *)malloc(sizeof(double) * (size_t)n), *rs = (double *)malloc(sizeof(double) * (size_t)n);
+    double *ys = (double *)calloc((size_t)n, sizeof(double)), *z = (double *)malloc(sizeof(double) * (size_t)n);
+    memcpy(w, b, sizeof(double) * (size_t)n);
+    memcpy(u, b, sizeof(double) * (size_t)n);
+    memcpy(rs, b, sizeof(double) * (size_t)n);
+    apply_precond(ls, cfg->precond, dinv, u, z, tmp);
+    orc_spmv(ls, z, v);                 /* v = A M^-1 u */
+    memcpy(au, v, sizeof(double) * (size_t)n);
+    double tau = r0, theta = 0.0, eta = 0.0, rho = dot(rs, w, n), alpha = 0.0;
+    while (iters < cfg->max_iterations) {
+      for (int half = 0; half < 2; ++half) {
+        if (half == 0) {
+          alpha = rho / dot(v, rs, n);
+        } else {
+          for (int64_t i = 0; i < n; ++i) u[i] = u[i] - alpha * v[i];
+          apply_precond(ls, cfg->precond, dinv, u, z, tmp);
+          orc_spmv(ls, z, au);          /* au = A M^-1 u */
+        }
+        for (int64_t i = 0; i < n; ++i) w[i] = w[i] - alpha * au[i];
+        const double dfac = theta * theta * eta / alpha;
+        for (int64_t i = 0; i < n; ++i) d[i] = u[i] + dfac * d[i];
+        theta = orc_norm2(w, n) / tau;
+        const double c = 1.0 / sqrt(1.0 + theta * theta);
+        tau = tau * theta * c;
+        eta = c * c * alpha;
+        for (int64_t i = 0; i < n; ++i) ys[i] = ys[i] + eta * d[i];
+        if (half == 1) {
+          const double rho_new = dot(rs, w, n);
+          const double beta = rho_new / rho;
+          rho = rho_new;
+          /* u = w + beta u ; v = A M^-1 u + beta (au + beta v) */
+          for (int64_t i = 0; i < n; ++i) u[i] = w[i] + beta * u[i];
+          for (int64_t i = 0; i < n; ++i) v[i] = beta * (au[i] + beta * v[i]);
+          apply_precond(ls, cfg->precond, dinv, u, z, tmp);
+          orc_spmv(ls, z, au);
+          for (int64_t i = 0; i < n; ++i) v[i] = au[i] + v[i];
+        }
+      }
+      ++iters;
+      const double rel = sqrt(2.0 * iters + 1.0) * tau / r0;
+      if (history && hl < history_cap) history[hl++] = rel;
+      if (rel <= cfg->tolerance) break;
+    }
+    apply_precond(ls, cfg->precond, dinv, ys, z, tmp); /* x = M^-1 (sum eta d) */
+    for (int64_t i = 0; i < n; ++i) x[i] = z[i];
+    free(w); free(u); free(v); free(d); free(au); free(rs); free(ys); free(z);
   } else {
     /* restarted right-preconditioned GMRES(m) with ICGS (Belos BlockGmres, block size 1) */
     const int m = cfg->kspace;

@@ -63,7 +63,7 @@ class SolverConfig(C.Structure):
                 ("max_iterations", C.c_int), ("kspace", C.c_int)]
 
 
-METHODS = {"cg": 0, "gmres": 1}
+METHODS = {"cg": 0, "gmres": 1, "biCgStab": 2, "bicgstab": 2, "tfqmr": 3}
 PRECONDS = {"none": 0, "jacobi": 1, "default": 1, "sgs": 2, "chebyshev": 3, "mt_sgs": 4}
 
 

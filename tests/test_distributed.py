@@ -25,7 +25,7 @@ def test_partition_and_halo_plan_gloo_cpu(nproc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,method", [(2, "gmres"), (2, "cg"), (3, "gmres")])
+@pytest.mark.parametrize("nproc,method", [(2, "gmres"), (2, "cg"), (3, "gmres"), (2, "tfqmr"), (3, "biCgStab")])
 def test_multirank_assemble_and_solve_on_one_gpu(nproc, method):
     _launch(nproc, "gpu", method)
 

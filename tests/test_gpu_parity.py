@@ -227,6 +227,14 @@ def _pin(ls, g, c, node=0):
     # Chebyshev(2, ratio 20, 15 power iterations): Ifpack2's algorithm restated (parity unpinned)
     ("cg", "chebyshev", dict(tolerance=1e-10, max_iterations=300)),
     ("gmres", "chebyshev", dict(tolerance=1e-10, max_iterations=200, kspace=50)),
+    # the other two Belos methods the regression inputs name (biCgStab: 1, tfqmr: 3; e.g.
+    # edgeHybridFluids.i:10 tfqmr + sgs): published algorithms restated, parity unpinned
+    ("biCgStab", "jacobi", dict(tolerance=1e-10, max_iterations=200)),
+    ("biCgStab", "sgs", dict(tolerance=1e-10, max_iterations=200)),
+    ("biCgStab", "none", dict(tolerance=1e-6, max_iterations=12)),
+    ("tfqmr", "jacobi", dict(tolerance=1e-10, max_iterations=200)),
+    ("tfqmr", "sgs", dict(tolerance=1e-5, max_iterations=50)),
+    ("tfqmr", "chebyshev", dict(tolerance=1e-10, max_iterations=200)),
 ])
 def test_solve_history_and_fields(G, torch, oracle, method, precond, kw):
     """config 2 in small: continuity assembly + pinned node, Jacobi-CG / GMRES."""
@@ -253,12 +261,16 @@ def test_solve_history_and_fields(G, torch, oracle, method, precond, kw):
     assert g.linearSolveIterations == ref["iters"]
     assert len(g.history) == len(ref["history"])
     # relative residual history to 1e-10 relative (BASELINE.json); entries near the
-    # stagnation floor (< 1e-12) only have to agree in magnitude
+    # stagnation floor (< 1e-12) only have to agree in magnitude.  BiCGStab / TFQMR: their short
+    # recurrences amplify the last-bit differences of the dot products (the device sums in a tree,
+    # the oracle sequentially) by ~1e6 over a solve with an erratic history, so their bar is 1e-7;
+    # iteration counts must still be equal.
+    tol_h = 1e-7 if method in ("biCgStab", "tfqmr") else TOL_SOLVE
     big = ref["history"] > 1e-11
     assert rel_err(g.history[big] / ref["history"][big], np.ones(big.sum())) <= 1e-7 or \
-        np.abs(g.history[big] - ref["history"][big]).max() <= TOL_SOLVE
-    assert np.abs(g.history - ref["history"]).max() <= TOL_SOLVE
-    assert rel_err(xout.cpu().numpy(), ref["x"]) <= max(TOL_SOLVE, 10 * kw["tolerance"] * 1e-3)
+        np.abs(g.history[big] - ref["history"][big]).max() <= tol_h
+    assert np.abs(g.history - ref["history"]).max() <= tol_h
+    assert rel_err(xout.cpu().numpy(), ref["x"]) <= max(tol_h, 10 * kw["tolerance"] * 1e-3)
     assert abs(g.linearResidual - ref["final_resid"]) <= TOL_SOLVE * max(1.0, np.linalg.norm(ls.owned_rhs()))
     assert abs(g.nonLinearResidual - np.linalg.norm(ls.owned_rhs())) <= 1e-12 * np.linalg.norm(ls.owned_rhs())
 
