@@ -328,6 +328,13 @@ int nalu_gpu_project_nodal_velocity(nalu_gpu_linsys *h, int64_t n, double dt, do
 int nalu_gpu_set_halo_plan(nalu_gpu_linsys *h, int n_neighbors, const int *neighbor_ranks,
                            const int *send_offsets, const int *send_lids,
                            const int *recv_offsets);
+/* The general form (Tpetra Import's permute-to list): recv_lids[i] is the shared / ghost column that
+ * the i-th received value lands in.  Needed when the shared-not-owned nodes (sorted by global id
+ * by the numbering rules) have several owners, e.g. a 2 x 2 x 2 block partition where a rank has
+ * up to seven neighbours.  recv_lids == NULL is nalu_gpu_set_halo_plan. */
+int nalu_gpu_set_halo_plan_indexed(nalu_gpu_linsys *h, int n_neighbors, const int *neighbor_ranks,
+                                   const int *send_offsets, const int *send_lids,
+                                   const int *recv_offsets, const int *recv_lids);
 /* the plan as set: pointers into the handle (valid until the next set_halo_plan / destroy) */
 int nalu_gpu_get_halo_plan(nalu_gpu_linsys *h, int *n_neighbors, const int **neighbor_ranks,
                            const int **send_offsets, const int **recv_offsets);

@@ -29,7 +29,7 @@ SYMBOLS = [
     "nalu_gpu_apply_dirichlet", "nalu_gpu_reset_rows", "nalu_gpu_load_complete",
     "nalu_gpu_solve", "nalu_gpu_spmv", "nalu_gpu_dot", "nalu_gpu_axpy", "nalu_gpu_norm2",
     "nalu_gpu_compute_mdot_edges", "nalu_gpu_nodal_grad_edges",
-    "nalu_gpu_field_axpby", "nalu_gpu_project_nodal_velocity", "nalu_gpu_compute_geometry_hex8", "nalu_gpu_set_halo_plan",
+    "nalu_gpu_field_axpby", "nalu_gpu_project_nodal_velocity", "nalu_gpu_compute_geometry_hex8", "nalu_gpu_set_halo_plan", "nalu_gpu_set_halo_plan_indexed",
     "nalu_gpu_set_comm", "nalu_gpu_set_callback_error", "nalu_gpu_get_halo_plan", "nalu_gpu_set_assembly_mode", "nalu_gpu_set_edge_ownership", "nalu_gpu_get_comm_buffers", "nalu_gpu_halo_exchange",
     "nalu_gpu_set_profiling", "nalu_gpu_get_timer", "nalu_gpu_reset_timers",
     "nalu_gpu_synchronize", "nalu_gpu_get_layout_info", "nalu_gpu_check_system", "nalu_gpu_set_debug", "nalu_gpu_dot_static",
@@ -155,6 +155,7 @@ def load():
         "nalu_gpu_field_axpby": [vp, i64, dbl, vp, dbl, vp],
         "nalu_gpu_project_nodal_velocity": [vp, i64, dbl, dbl, Vec3, Vec3, vp, vp, Vec3],
         "nalu_gpu_set_halo_plan": [vp, ci, vp, vp, vp, vp],
+        "nalu_gpu_set_halo_plan_indexed": [vp, ci, vp, vp, vp, vp, vp],
         "nalu_gpu_set_comm": [vp, P(Comm)],
         "nalu_gpu_set_callback_error": [C.c_char_p],
         "nalu_gpu_get_halo_plan": [vp, P(ci), P(vp), P(vp), P(vp)],

@@ -162,3 +162,141 @@ class BoxSlab:
         area[1, d == 1] = (hx * hz * fx[L] * fz[L])[d == 1]
         area[2, d == 2] = (hx * hy * fx[L] * fy[L])[d == 2]
         return vol, area
+
+
+class BoxBlock:
+    """Rank `rank` of a (px, py, pz) block partition of a box with (nxn, nyn, nzn) nodes: every
+    rank gets a brick of elements, a node on a cut plane is owned by the lowest rank that holds it
+    (the reference's STK rule), so a rank has up to 7 neighbours on a 2 x 2 x 2 partition -- one
+    per xGMI link of an 8-GPU node.  Same attributes as BoxSlab; the
+    shared-not-owned nodes (sorted by global id, src/TpetraLinearSystem.C:247-285) have several
+    owners here, so the halo plan carries a receive index list (`recv_lids`,
+    nalu_gpu_set_halo_plan_indexed)."""
+
+    def __init__(self, nxn, nyn, nzn, rank, parts, lengths=(1.0, 1.0, 1.0), edge_order="sorted"):
+        self.dims = (nxn, nyn, nzn)
+        self.parts = parts
+        self.rank, self.nranks, self.lengths = rank, parts[0] * parts[1] * parts[2], lengths
+        info = self._rank_nodes(rank)
+        own, sh, gh = info["owned"], info["shared"], info["ghost"]
+        self.n_owned, self.n_shared, self.n_ghost = len(own[0]), len(sh[0]), len(gh[0])
+        self.n_local = self.n_owned + self.n_shared + self.n_ghost
+        self.gids = np.concatenate([own[0], sh[0], gh[0]])
+        self.owners = np.concatenate([own[1], sh[1], gh[1]]).astype(np.int32)
+        g0 = self.gids - 1
+        self.i = (g0 % nxn).astype(np.int32)
+        self.j = ((g0 // nxn) % nyn).astype(np.int32)
+        self.k = (g0 // (nxn * nyn)).astype(np.int32)
+        lid_of = {int(g): n for n, g in enumerate(self.gids)}
+        # local edges: every lattice edge with an owned end, oriented low gid -> high gid, sorted (L, R)
+        ed, en = [], []
+        step = (1, nxn, nxn * nyn)
+        lim = (nxn, nyn, nzn)
+        idx = (self.i, self.j, self.k)
+        for n in range(self.n_owned):
+            g = int(self.gids[n])
+            for d in range(3):
+                if idx[d][n] + 1 < lim[d]:
+                    en.append((n, lid_of[g + step[d]])); ed.append(d)
+                if idx[d][n] > 0:
+                    m = lid_of[g - step[d]]
+                    if m >= self.n_owned:  # (owned-owned edges are listed from their lower end)
+                        en.append((m, n)); ed.append(d)
+        en, ed = np.array(en, np.int64).reshape(-1, 2), np.array(ed, np.int8)
+        gl, gr = self.gids[en[:, 0]], self.gids[en[:, 1]]
+        o = np.lexsort((gr, gl))
+        if edge_order == "slot":
+            o = o[np.argsort(ed[o], kind="stable")]
+        self.edge_nodes = np.ascontiguousarray(en[o].astype(np.int32))
+        self.edge_dir = ed[o]
+        self.n_edges = len(ed)
+        # halo plan: what each neighbour holds of mine, in ITS local order; what I hold of its
+        nbrs = sorted(set(int(r) for r in self.owners[self.n_owned:]) |
+                      set(q for q in self._adjacent_ranks() if self._needs_from(q, rank)))
+        so, sl, ro, rl = [0], [], [0], []
+        for q in nbrs:
+            theirs = self._rank_nodes(q)
+            tg = np.concatenate([theirs["shared"][0], theirs["ghost"][0]])
+            to = np.concatenate([theirs["shared"][1], theirs["ghost"][1]])
+            send = [lid_of[int(g)] for g in tg[to == rank]]
+            sl += send
+            so.append(so[-1] + len(send))
+            mine = np.nonzero(self.owners[self.n_owned:] == q)[0] + self.n_owned
+            rl += [int(c) for c in mine]
+            ro.append(ro[-1] + len(mine))
+        keep = [n for n in range(len(nbrs)) if so[n + 1] > so[n] or ro[n + 1] > ro[n]]
+        self.neighbors = np.array([nbrs[n] for n in keep], np.int32)
+        self.send_offsets = np.array([0] + [so[n + 1] for n in keep], np.int32)
+        self.recv_offsets = np.array([0] + [ro[n + 1] for n in keep], np.int32)
+        self.send_lids = np.array(sl, np.int32)
+        self.recv_lids = np.array(rl, np.int32)
+
+    # ---- partition geometry
+    def _coords_of(self, rank):
+        px, py, _ = self.parts
+        return rank % px, (rank // px) % py, rank // (px * py)
+
+    def _elem_ranges(self, rank):
+        return [split_elems(self.dims[d] - 1, self.parts[d])[c] for d, c in enumerate(self._coords_of(rank))]
+
+    def _adjacent_ranks(self):
+        px, py, pz = self.parts
+        a, b, c = self._coords_of(self.rank)
+        out = []
+        for dc in (-1, 0, 1):
+            for db in (-1, 0, 1):
+                for da in (-1, 0, 1):
+                    x, y, z = a + da, b + db, c + dc
+                    if (da or db or dc) and 0 <= x < px and 0 <= y < py and 0 <= z < pz:
+                        out.append(x + px * (y + py * z))
+        return out
+
+    def _needs_from(self, q, owner):
+        t = self._rank_nodes(q)
+        return bool((np.concatenate([t["shared"][1], t["ghost"][1]]) == owner).any())
+
+    def _owner_of(self, i, j, k):
+        """lowest rank whose element brick holds node (i, j, k)"""
+        c = []
+        for d, v in enumerate((i, j, k)):
+            rng = split_elems(self.dims[d] - 1, self.parts[d])
+            c.append(min(p for p, (e0, e1) in enumerate(rng) if e0 <= v <= e1))
+        return c[0] + self.parts[0] * (c[1] + self.parts[1] * c[2])
+
+    def _rank_nodes(self, rank):
+        cache = self.__dict__.setdefault("_cache", {})
+        if rank in cache:
+            return cache[rank]
+        nxn, nyn, nzn = self.dims
+        er = self._elem_ranges(rank)
+        gid = lambda i, j, k: 1 + i + nxn * (j + nyn * k)
+        owned, shared = [], []
+        for k in range(er[2][0], er[2][1] + 1):
+            for j in range(er[1][0], er[1][1] + 1):
+                for i in range(er[0][0], er[0][1] + 1):
+                    o = self._owner_of(i, j, k)
+                    (owned if o == rank else shared).append((gid(i, j, k), o))
+        ownset = {g for g, _ in owned}
+        held = ownset | {g for g, _ in shared}
+        ghost = {}
+        step = (1, nxn, nxn * nyn)
+        for g, _ in owned:  # lattice neighbours of owned nodes outside the brick
+            i, j, k = (g - 1) % nxn, ((g - 1) // nxn) % nyn, (g - 1) // (nxn * nyn)
+            for d, (v, lim) in enumerate(((i, nxn), (j, nyn), (k, nzn))):
+                for s in (-1, 1):
+                    if 0 <= v + s < lim and g + s * step[d] not in held:
+                        h = g + s * step[d]
+                        hi, hj, hk = (h - 1) % nxn, ((h - 1) // nxn) % nyn, (h - 1) // (nxn * nyn)
+                        ghost[h] = self._owner_of(hi, hj, hk)
+        srt = lambda lst, key: (np.array([g for g, _ in sorted(lst, key=key)], np.int64),
+                                np.array([o for _, o in sorted(lst, key=key)], np.int64))
+        out = dict(owned=srt(owned, lambda t: t[0]), shared=srt(shared, lambda t: t[0]),
+                   ghost=srt(list(ghost.items()), lambda t: (t[1], t[0])))
+        cache[rank] = out
+        return out
+
+    # ---- geometry (as BoxSlab)
+    spacing = BoxSlab.spacing
+    coords = BoxSlab.coords
+    _frac = BoxSlab._frac
+    uniform_geometry = BoxSlab.uniform_geometry

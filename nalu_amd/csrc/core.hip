@@ -168,7 +168,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   NG_FREE(h->dY); NG_FREE(h->dList); NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf);
-  NG_FREE(h->dRecvBuf); NG_FREE(h->dEdgeOwned); NG_FREE(h->dExpSendRow); NG_FREE(h->dExpRecvRow);
+  NG_FREE(h->dRecvBuf); NG_FREE(h->dRecvLids); NG_FREE(h->dEdgeOwned); NG_FREE(h->dExpSendRow); NG_FREE(h->dExpRecvRow);
   NG_FREE(h->dExpRecvPos); NG_FREE(h->dExpSend); NG_FREE(h->dExpRecv);
   if (h->hPinned) (void)hipHostFree(h->hPinned);
   if (h->ownStream) (void)hipStreamDestroy(h->stream);
@@ -1352,6 +1352,13 @@ extern "C" int nalu_gpu_set_halo_plan(nalu_gpu_linsys *h, int n_nbr, const int *
                                       const int *send_offsets, const int *send_lids,
                                       const int *recv_offsets)
 {
+  return nalu_gpu_set_halo_plan_indexed(h, n_nbr, nbr_ranks, send_offsets, send_lids, recv_offsets, nullptr);
+}
+
+extern "C" int nalu_gpu_set_halo_plan_indexed(nalu_gpu_linsys *h, int n_nbr, const int *nbr_ranks,
+                                              const int *send_offsets, const int *send_lids,
+                                              const int *recv_offsets, const int *recv_lids)
+{
   NG_FINALIZED(h);
   NG_REQUIRE(n_nbr >= 0, NALU_GPU_EINVAL, "bad neighbour count");
   NG_REQUIRE(n_nbr == 0 || (nbr_ranks && send_offsets && recv_offsets), NALU_GPU_EINVAL, "null plan");
@@ -1365,8 +1372,18 @@ extern "C" int nalu_gpu_set_halo_plan(nalu_gpu_linsys *h, int n_nbr, const int *
   for (int p = 0; p < n_nbr; ++p)
     NG_REQUIRE(send_offsets[p] <= send_offsets[p + 1] && recv_offsets[p] <= recv_offsets[p + 1],
                NALU_GPU_EINVAL, "offsets must be non-decreasing");
+  if (recv_lids) {  // every shared / ghost column receives exactly one value
+    std::vector<char> seen((size_t)std::max<int64_t>(nr, 1), 0);
+    for (int64_t i = 0; i < nr; ++i) {
+      const int c = recv_lids[i];
+      NG_REQUIRE(c >= h->nOwned && c < h->nCols && !seen[c - h->nOwned], NALU_GPU_EINVAL,
+                 "receive list entry %lld (column %d) is not a shared / ghost column, or is named twice",
+                 (long long)i, c);
+      seen[c - h->nOwned] = 1;
+    }
+  }
   NG_HIP(hipStreamSynchronize(h->stream));
-  NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf); NG_FREE(h->dRecvBuf);
+  NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf); NG_FREE(h->dRecvBuf); NG_FREE(h->dRecvLids);
   h->nNbr = n_nbr;
   h->nbrRanks.assign(nbr_ranks, nbr_ranks + n_nbr);
   h->sendOff.assign(send_offsets, send_offsets + n_nbr + (n_nbr ? 1 : 0));
@@ -1377,6 +1394,11 @@ extern "C" int nalu_gpu_set_halo_plan(nalu_gpu_linsys *h, int n_nbr, const int *
   NG_HIP(hipMalloc(&h->dSendBuf, sizeof(double) * (size_t)std::max<int64_t>(ns, 1)));
   NG_HIP(hipMalloc(&h->dRecvBuf, sizeof(double) * (size_t)std::max<int64_t>(nr, 1)));
   if (ns) NG_HIP(hipMemcpy(h->dSendLids, send_lids, sizeof(int) * (size_t)ns, hipMemcpyHostToDevice));
+  if (recv_lids && nr) {
+    NG_HIP(hipMalloc(&h->dRecvLids, sizeof(int) * (size_t)nr));
+    NG_HIP(hipMemcpy(h->dRecvLids, recv_lids, sizeof(int) * (size_t)nr, hipMemcpyHostToDevice));
+  }
+  h->exportReady = false;
   return NALU_GPU_OK;
 }
 
@@ -1428,6 +1450,12 @@ __global__ void k_pack(long long n, const int *lids, const double *vec, double *
   if (i < n) buf[i] = vec[lids[i]];
 }
 
+__global__ void k_unpack(long long n, const int *lids, const double *buf, double *vec)
+{
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) vec[lids[i]] = buf[i];
+}
+
 int nalu_gpu::halo_begin(nalu_gpu_linsys *h, const double *vec)
 {
   if (h->nCols == h->nOwned) return NALU_GPU_OK;
@@ -1448,6 +1476,12 @@ int nalu_gpu::halo_end(nalu_gpu_linsys *h, double *vec)
   if (h->nCols == h->nOwned) return NALU_GPU_OK;
   NG_REQUIRE(h->comm.exchange_end(h->comm.ctx, h->stream) == 0, NALU_GPU_EHIP,
              "exchange_end callback failed: %s", callback_error());
+  if (h->dRecvLids) {  // indexed plan: the shared / ghost columns are not grouped by sender
+    k_unpack<<<(unsigned)((h->recvCount + 255) / 256), 256, 0, h->stream>>>(h->recvCount, h->dRecvLids, h->dRecvBuf,
+                                                                            vec);
+    NG_HIP(hipGetLastError());
+    return NALU_GPU_OK;
+  }
   NG_HIP(hipMemcpyAsync(vec + h->nOwned, h->dRecvBuf, sizeof(double) * (size_t)h->recvCount,
                         hipMemcpyDeviceToDevice, h->stream));
   return NALU_GPU_OK;

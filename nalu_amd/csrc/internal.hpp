@@ -217,6 +217,7 @@ struct nalu_gpu_linsys {
   int nNbr = 0;
   std::vector<int> nbrRanks, sendOff, recvOff;
   int *dSendLids = nullptr;
+  int *dRecvLids = nullptr;  // indexed halo plan: column of every received value (null: contiguous)
   double *dSendBuf = nullptr, *dRecvBuf = nullptr;
   int64_t sendCount = 0, recvCount = 0;
   nalu_gpu_comm comm{};

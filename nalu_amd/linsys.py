@@ -447,11 +447,16 @@ class GpuLinearSystem:
             self.h, n, dt, gamma1, _vec3(dpdx_new), _vec3(dpdx_old), _ptr(density),
             _ptr(projected), _vec3(velocity)))
 
-    def set_halo_plan(self, neighbor_ranks, send_offsets, send_lids, recv_offsets):
+    def set_halo_plan(self, neighbor_ranks, send_offsets, send_lids, recv_offsets, recv_lids=None):
         nb = _np(neighbor_ranks, np.int32)
         so, sl, ro = _np(send_offsets, np.int32), _np(send_lids, np.int32), _np(recv_offsets, np.int32)
-        L.check(self.lib.nalu_gpu_set_halo_plan(self.h, len(nb), nb.ctypes.data, so.ctypes.data,
-                                                sl.ctypes.data, ro.ctypes.data))
+        if recv_lids is None:
+            L.check(self.lib.nalu_gpu_set_halo_plan(self.h, len(nb), nb.ctypes.data, so.ctypes.data,
+                                                    sl.ctypes.data, ro.ctypes.data))
+        else:  # the general (indexed) form: several owners among the shared-not-owned nodes
+            rl = _np(recv_lids, np.int32)
+            L.check(self.lib.nalu_gpu_set_halo_plan_indexed(self.h, len(nb), nb.ctypes.data, so.ctypes.data,
+                                                            sl.ctypes.data, ro.ctypes.data, rl.ctypes.data))
 
     def comm_buffers(self):
         sb, rb, red = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -22,9 +22,13 @@ import nalu_amd  # noqa: E402
 from nalu_amd.comm import exchange_halo  # noqa: E402
 
 
-def plan_test(rank, world):
+def plan_test(rank, world, block=False):
     dims = (5, 4, 11)
-    S = nalu_amd.BoxSlab(*dims, rank, world)
+    if block:
+        from nalu_amd.box import BoxBlock
+        S = BoxBlock(*dims, rank, (2, 2, 2))
+    else:
+        S = nalu_amd.BoxSlab(*dims, rank, world)
     # partition invariants
     tot = torch.tensor([S.n_owned], dtype=torch.int64)
     dist.all_reduce(tot)
@@ -43,7 +47,11 @@ def plan_test(rank, world):
     recv = torch.zeros(S.n_local - S.n_owned, dtype=torch.float64)
     for w in exchange_halo(send, recv, S.neighbors, S.send_offsets, S.recv_offsets):
         w.wait()
-    vec[S.n_owned:] = recv
+    if block:  # several owners among the shared nodes: the receive buffer is neighbour-major
+        assert sorted(S.recv_lids.tolist()) == list(range(S.n_owned, S.n_local))
+        vec[torch.as_tensor(S.recv_lids.astype(np.int64))] = recv
+    else:
+        vec[S.n_owned:] = recv
     assert np.array_equal(vec.numpy(), f(S.gids))
     # all-reduce of owned partial dots == global dot
     part = torch.tensor([float((vec[:S.n_owned] ** 2).sum())], dtype=torch.float64)
@@ -64,13 +72,19 @@ def plan_test(rank, world):
     assert np.array_equal(cnt.numpy(), deg.reshape(-1).astype(float))
 
 
-def gpu_test(rank, world, method):
+def gpu_test(rank, world, method, block=False):
     from oracle import pyoracle as po
     from common import Case, rel_err
     from nalu_amd.comm import TorchComm
     dims = (9, 8, 23)
     c = Case(po, 0, 0.125, dims=dims)
-    S = nalu_amd.BoxSlab(*dims, rank, world)
+    if block:  # 2 x 2 x 2 bricks: up to 7 neighbours per rank, several owners among the shared nodes
+        from nalu_amd.box import BoxBlock
+        assert world == 8
+        S = BoxBlock(*dims, rank, (2, 2, 2))
+        assert max(len(BoxBlock(*dims, r, (2, 2, 2)).neighbors) for r in (0, 7)) == 7
+    else:
+        S = nalu_amd.BoxSlab(*dims, rank, world)
     gi = S.gids - 1  # local -> global node index
     # local edge -> global edge index through the (L,R)-sorted global edge list
     key = c.m.edge_nodes[:, 0].astype(np.int64) * c.m.nnodes + c.m.edge_nodes[:, 1]
@@ -89,7 +103,7 @@ def gpu_test(rank, world, method):
     g.beginLinearSystemConstruction(S.n_owned, S.n_shared, S.n_ghost, S.gids, S.owners, rank)
     g.buildEdgeToNodeGraph(S.edge_nodes)
     g.finalizeLinearSystem()
-    g.set_halo_plan(S.neighbors, S.send_offsets, S.send_lids, S.recv_offsets)
+    g.set_halo_plan(S.neighbors, S.send_offsets, S.send_lids, S.recv_offsets, getattr(S, "recv_lids", None))
     # NALU_TEST_NATIVE_RCCL=1: the callbacks are libnalu_gpu_rccl.so's (ncclAllReduce / grouped
     # ncclSend+ncclRecv called straight from the library) instead of torch.distributed's
     native = os.environ.get("NALU_TEST_NATIVE_RCCL") == "1"
@@ -306,6 +320,10 @@ def main():
         plan_test(rank, world)
     elif mode == "export":
         export_test(rank, world)
+    elif mode == "plan_block":
+        plan_test(rank, world, block=True)
+    elif mode == "block":
+        gpu_test(rank, world, sys.argv[2], block=True)
     else:
         gpu_test(rank, world, sys.argv[2])
     dist.barrier()

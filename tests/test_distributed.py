@@ -24,6 +24,11 @@ def test_partition_and_halo_plan_gloo_cpu(nproc):
     _launch(nproc, "plan")
 
 
+def test_block_partition_2x2x2_plan_gloo_cpu():
+    """BoxBlock (2 x 2 x 2 bricks, up to 7 neighbours, indexed receive list) on 8 gloo ranks."""
+    _launch(8, "plan_block")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("nproc,method", [(2, "gmres"), (2, "cg"), (3, "gmres"), (2, "tfqmr"), (3, "biCgStab")])
 def test_multirank_assemble_and_solve_on_one_gpu(nproc, method):
@@ -47,6 +52,15 @@ def test_comm_on_a_non_default_stream(nproc, backend):
     the TorchComm callbacks switch to the library's stream, so halos and dot products are ordered
     after the kernels that produce them (same results as on the default stream)."""
     _launch(nproc, "gpu", "cg", backend=backend, side_stream=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["gmres", "cg"])
+def test_block_partition_2x2x2_on_one_gpu(method):
+    """2 x 2 x 2 bricks (7 neighbours = the 7 xGMI links of a GPU): eight gloo ranks
+    share the one GPU of the test box; indexed halo plan (the shared-not-owned nodes of a rank have
+    up to 7 owners); owned rows, solution and residual history against the np = 1 oracle."""
+    _launch(8, "block", method, timeout=400)
 
 
 @pytest.mark.gpu
