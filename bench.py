@@ -96,7 +96,7 @@ class RankSystem:
         self.comm_kind = "none"
         if nranks > 1:
             g.set_halo_plan(S.neighbors, S.send_offsets, S.send_lids, S.recv_offsets)
-            if backend == "nccl":
+            if backend == "nccl" and world is not None:
                 self.comm = world.attach(g)  # libnalu_gpu_rccl.so: native RCCL callbacks
                 self.comm_kind = "rccl-native"
             else:
@@ -263,8 +263,22 @@ def main():
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(device))
-            from nalu_amd.rccl import RcclWorld
-            rworld = RcclWorld(rank, world, local)  # the library's own communicator
+            # the library's own communicator (no Python per iteration); NALU_BENCH_COMM=torch, or a
+            # failure to set it up on ANY rank, selects the torch.distributed callbacks instead
+            ok = 0
+            if os.environ.get("NALU_BENCH_COMM", "native") == "native":
+                try:
+                    from nalu_amd.rccl import RcclWorld
+                    rworld = RcclWorld(rank, world, local)
+                    ok = 1
+                except Exception as e:  # noqa: BLE001 (reported, then the fallback runs)
+                    print(f"[bench] rank {rank}: native RCCL communicator unavailable ({e}); "
+                          f"falling back to torch.distributed", file=sys.stderr, flush=True)
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and rworld is not None:
+                rworld.close()
+                rworld = None
         else:
             dist.init_process_group(backend)
 

@@ -382,6 +382,174 @@ __global__ __launch_bounds__(SELL_C, ORDERED ? Op::kOrderedWaves : 1) void k_ass
   else rhs[row] += b;
 }
 
+// Burst row gather (slices of at most BURST_W entries, default when it applies): the same rows,
+// fluxes and summation order as k_assemble_rows<..., false>, bit for bit, but a row's loads are
+// issued together instead of one dependent round trip per entry.  Each lane first lists its edge
+// entries in CSR order (computed from the slice's tag / column offsets; the irregular rows load
+// their tags and columns); the lists are the order of evaluation, so the diagonal / rhs sums see
+// the same additions in the same order.  Then NB edges at a time: edge data and neighbour nodes
+// of all NB in flight at once, NB fluxes, NB stores.  No LDS and no barrier: a neighbour whose row
+// is held by another lane of the same wave comes from that lane's registers (ds_bpermute), the
+// others from memory.  The row kernel is bound by its ~8 dependent round trips per row with 20
+// waves per CU; this one needs 1-2 with 8-12 waves.
+#ifndef BURST_NB
+#define BURST_NB 6
+#define BURST_WAVES 2
+#endif
+template <class Op> struct BurstCfg { static constexpr int NB = BURST_NB, WAVES = BURST_WAVES; };
+template <> struct BurstCfg<ScalOp> { static constexpr int NB = 3, WAVES = 2; };
+
+template <class Op, bool SET>
+__global__ __launch_bounds__(SELL_C, BurstCfg<Op>::WAVES) void k_assemble_rows_burst(SellView A, typename Op::Params P,
+                                                                                 double *__restrict__ rhs)
+{
+  using Node = typename Op::Node;
+  using Edge = typename Op::Edge;
+  constexpr int NF = sizeof(Node) / sizeof(double);
+  constexpr int NB = BurstCfg<Op>::NB;
+  constexpr int NE = BURST_NE;  // edges per row taken by the bursts; further ones go through the tail loop
+  const int slice = sched_slice(A, blockIdx.x);
+  const int r = threadIdx.x;
+  const int sBase = slice * SELL_C;
+  const int row = sBase + r;
+  const bool live = row < A.nRows;
+  const int waveRow0 = sBase + (r & ~63);
+  // (wave-uniform addresses: three 64-byte scalar loads, issued together with the row's own data)
+  const int wv = __builtin_amdgcn_readfirstlane(r >> 6);
+  const BurstSlice *const S = A.burst + slice;
+  const BurstRow D = S->reg, X = S->irr[wv];
+  const long long off = S->off;
+  const int w = S->w;
+  const unsigned long long mI = S->irrMask[wv];
+  const long long pos0 = off + r;
+  Node own;
+  if (live) own = Op::load(P, row);
+  const bool irregular = (mI >> (r & 63)) & 1ULL;  // (only rows of the matrix are flagged)
+  // ---- the lane's entries: edges in CSR order (id + R bit, column, entry index), the diagonal,
+  // and the entries a SET pass has to zero.  Regular rows: the slice's list; a wave's one
+  // irregular row: its list comes with the descriptor; several: they read their tags and columns.
+  const bool isX = irregular && X.lane < 64u;
+  unsigned eid[NE], kk[NE];
+  int cl[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    kk[e] = ((isX ? X.kl : D.kl) >> (4 * e)) & 15u;
+    eid[e] = isX ? X.tb[e] : D.tb[e] + (unsigned)row;
+    cl[e] = isX ? X.ko[e] : row + D.ko[e];
+  }
+  const unsigned info = isX ? X.info : D.info;
+  int ne = live ? (int)(info & 15u) : 0;
+  int kDiag = (int)((info >> 4) & 15u) - 1;
+  unsigned zeroMask = (info >> 8) & 255u, lateMask = (info >> 16) & 255u;
+  if (X.lane == BURST_IRR_MANY) {
+    // irregular rows read their tags and columns and compact them (all loads first)
+    unsigned tg[BURST_W];
+    int cc[BURST_W];
+#pragma unroll
+    for (int k = 0; k < BURST_W; ++k) {
+      tg[k] = TAG_PAD;
+      cc[k] = row;
+      if (k < w && irregular) {
+        const long long pos = pos0 + (long long)k * SELL_C;
+        tg[k] = A.tags[pos];
+        cc[k] = A.cols[pos];
+      }
+    }
+    if (irregular) {
+      ne = 0;
+      kDiag = -1;
+      zeroMask = lateMask = 0;
+#pragma unroll
+      for (int k = 0; k < BURST_W; ++k) {
+        const bool isE = tg[k] < TAG_OTHER;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const bool take = isE && ne == e;
+          eid[e] = take ? tg[k] : eid[e];
+          cl[e] = take ? cc[k] : cl[e];
+          kk[e] = take ? (unsigned)k : kk[e];
+        }
+        if (isE && ne >= NE) lateMask |= 1u << k;
+        ne += isE ? 1 : 0;
+        if (tg[k] == TAG_DIAG) kDiag = k;
+        else if (!isE && k < w) zeroMask |= 1u << k;
+      }
+    }
+  }
+  double diag = 0.0, b = 0.0;
+  // ---- bursts of NB edges
+#pragma unroll
+  for (int e0 = 0; e0 < NE; e0 += NB) {
+    if (__ballot(ne > e0) == 0ULL) break;
+    Edge E[NB];
+    Node nb[NB];
+    bool inWave[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = e0 + i;
+      const bool act = e < ne;
+      // the neighbour's row sits in another lane of this wave: its registers hold the data
+      inWave[i] = act && (unsigned)(cl[e] - waveRow0) < 64u && cl[e] < A.nRows;
+      if (act) {
+        E[i] = Op::load_edge(P, (long long)(eid[e] & 0x7FFFFFFFu));
+        if (!inWave[i]) nb[i] = Op::load(P, cl[e]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = e0 + i;
+      if (__ballot(inWave[i]) != 0ULL) {
+        const double *po = reinterpret_cast<const double *>(&own);
+        double *pn = reinterpret_cast<double *>(&nb[i]);
+        const int src = (cl[e] - waveRow0) & 63;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const double v = __shfl(po[f], src, 64);
+          pn[f] = inWave[i] ? v : pn[f];
+        }
+      }
+      if (e < ne) {
+        double lhs[4], rh[2];
+        Op::edge(P, Op::mirrored(E[i], (eid[e] >> 31) != 0), own, nb[i], lhs, rh);
+        diag += lhs[0];
+        b += rh[0];
+        const long long pos = pos0 + (long long)kk[e] * SELL_C;
+        if (SET) A.vals[pos] = lhs[1];
+        else A.vals[pos] += lhs[1];
+      }
+    }
+  }
+  // ---- rows with more than NE edges: the remaining ones one at a time
+  if (__ballot(lateMask != 0u) != 0ULL) {
+    for (int k = 0; k < w; ++k) {
+      if (!((lateMask >> k) & 1u)) continue;
+      const long long pos = pos0 + (long long)k * SELL_C;
+      // (the tag / column arrays hold every entry, also those of the regular rows)
+      const unsigned tag = A.tags[pos];
+      const int c = A.cols[pos];
+      double lhs[4], rh[2];
+      Op::edge(P, Op::mirrored(Op::load_edge(P, (long long)(tag & 0x7FFFFFFFu)), (tag >> 31) != 0), own,
+               Op::load(P, c), lhs, rh);
+      diag += lhs[0];
+      b += rh[0];
+      if (SET) A.vals[pos] = lhs[1];
+      else A.vals[pos] += lhs[1];
+    }
+  }
+  if (!live) return;
+  if (SET) {
+    for (int k = 0; k < w; ++k)
+      if ((zeroMask >> k) & 1u) A.vals[pos0 + (long long)k * SELL_C] = 0.0;
+  }
+  if (kDiag >= 0) {
+    const long long pos = pos0 + (long long)kDiag * SELL_C;
+    if (SET) A.vals[pos] = diag;
+    else A.vals[pos] += diag;
+  }
+  if (SET) rhs[row] = b;
+  else rhs[row] += b;
+}
+
 // Entry-parallel row gather, persistent: a workgroup of NW waves assembles one QUARTER slice
 // (64 rows) per iteration; wave k evaluates the k-th entry of those 64 rows (for w > NW:
 // entries k, k + NW, ...), so the loads of a row's edges -- edge data and out-of-quarter
@@ -587,6 +755,9 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
       int grid = std::max(1, perCu) * std::max(1, cus);
       grid = std::min((grid + 7) / 8 * 8, (nQ + 7) / 8 * 8);
       kern<<<grid, QROWS * 8, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+    } else if (h->asmVariant == 3 && h->dBurst && !h->dEdgeOwned) {
+      if (set) k_assemble_rows_burst<Op, true><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+      else k_assemble_rows_burst<Op, false><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
     } else if (h->asmVariant == 2) {
       // NG_ASM_ORDER=1: the slice's out-of-slice entries first (k_slice_order).  HBM traffic falls
       // from 7.3 to 4.7 GB per launch at 256^3, but the 18 extra registers cost a wave per SIMD

@@ -165,7 +165,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dTags); NG_FREE(h->dDiagPos); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
-  NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
+  NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dBurst); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   NG_FREE(h->dY); NG_FREE(h->dList); NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf);
   NG_FREE(h->dRecvBuf); NG_FREE(h->dRecvLids); NG_FREE(h->dEdgeOwned); NG_FREE(h->dExpSendRow); NG_FREE(h->dExpRecvRow);
@@ -395,6 +395,84 @@ __global__ void k_tag_edges(long long nEdges, const int *eL, const int *eR, int 
       tags[pos] = (unsigned)e | 0x80000000u;
     }
   }
+}
+
+// burst-assembly descriptor of every slice (BurstSlice): which entries of a regular row are edges,
+// in CSR order, with their tag and column offsets; the same list for a wave's irregular row when it
+// has exactly one (read from the tag / column arrays here, so that the kernel need not)
+__device__ void burst_row_finish(BurstRow &R, unsigned ne, unsigned kd, unsigned zm, unsigned lm)
+{
+  R.info = ne | (kd << 4) | (zm << 8) | (lm << 16);
+}
+
+__global__ void k_burst_desc(int nSlices, int nRows, const long long *sliceOff, const int *sliceWidth, const int *kOff,
+                             const unsigned *tBase, const unsigned *tMul, const unsigned long long *exMask,
+                             const unsigned long long *exMaskT, const unsigned *tags, const int *cols,
+                             BurstSlice *out)
+{
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nSlices) return;
+  const long long off = sliceOff[s], o = off / SELL_C;
+  const int w = sliceWidth[s];
+  BurstSlice D;
+  memset(&D, 0, sizeof(D));
+  D.off = off;
+  D.w = w;
+  {
+    unsigned ne = 0, kd = 0, zm = 0, lm = 0;
+    for (int k = 0; k < w && k < BURST_W; ++k) {
+      if (tMul[o + k] == 1u) {
+        if (ne < (unsigned)BURST_NE) {
+          D.reg.kl |= (unsigned)k << (4 * ne);
+          D.reg.tb[ne] = tBase[o + k];
+          D.reg.ko[ne] = kOff[o + k];
+        } else {
+          lm |= 1u << k;
+        }
+        ++ne;
+      } else if (tBase[o + k] == TAG_DIAG) {
+        kd = (unsigned)k + 1;
+      } else {
+        zm |= 1u << k;
+      }
+    }
+    burst_row_finish(D.reg, ne, kd, zm, lm);
+  }
+  for (int wv = 0; wv < 4; ++wv) {
+    unsigned long long m = exMask[(size_t)s * 4 + wv] | exMaskT[(size_t)s * 4 + wv];
+    // (rows past the end of the matrix are not rows)
+    const long long row0 = (long long)s * SELL_C + wv * 64;
+    if (row0 + 64 > nRows) m &= row0 >= nRows ? 0ULL : ((1ULL << (nRows - row0)) - 1ULL);
+    D.irrMask[wv] = m;
+    BurstRow &R = D.irr[wv];
+    R.lane = m == 0ULL ? BURST_IRR_NONE : BURST_IRR_MANY;
+    if (m != 0ULL && (m & (m - 1ULL)) == 0ULL) {
+      int lane = 0;
+      while (!((m >> lane) & 1ULL)) ++lane;
+      R.lane = (unsigned)lane;
+      const long long p0 = off + wv * 64 + lane;
+      unsigned ne = 0, kd = 0, zm = 0, lm = 0;
+      for (int k = 0; k < w && k < BURST_W; ++k) {
+        const unsigned tag = tags[p0 + (long long)k * SELL_C];
+        if (tag < TAG_OTHER) {
+          if (ne < (unsigned)BURST_NE) {
+            R.kl |= (unsigned)k << (4 * ne);
+            R.tb[ne] = tag;
+            R.ko[ne] = cols[p0 + (long long)k * SELL_C];
+          } else {
+            lm |= 1u << k;
+          }
+          ++ne;
+        } else if (tag == TAG_DIAG) {
+          kd = (unsigned)k + 1;
+        } else {
+          zm |= 1u << k;
+        }
+      }
+      burst_row_finish(R, ne, kd, zm, lm);
+    }
+  }
+  out[s] = D;
 }
 
 // Tag-offset compression (the assembly kernels' counterpart of the column offsets, see
@@ -658,6 +736,7 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
   // experimental variants of the row-gather assembly, read once here
   if (const char *e = getenv("NG_ASM_ENTRIES")) h->asmVariant = atoi(e) ? 1 : 0;
   if (const char *e = getenv("NG_ASM_ORDER")) h->asmVariant = atoi(e) ? 2 : h->asmVariant;
+  if (const char *e = getenv("NG_ASM_BURST")) h->asmVariant = atoi(e) ? 3 : h->asmVariant;
 
   // edges: SoA copy on the device + per-entry edge tags
   if (h->nEdges > 0) {
@@ -716,6 +795,13 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
       k_slice_order<<<(h->nSlices + 255) / 256, 256, 0, h->stream>>>(h->nSlices, h->dSliceOff, h->dSliceWidth,
                                                                       h->dKOff, h->dTBase, h->dTMul,
                                                                       h->dOrdWord, on);
+    NG_HIP(hipGetLastError());
+  }
+  if (h->nSlices > 0 && h->maxSliceWidth <= BURST_W) {
+    NG_HIP(hipMalloc(&h->dBurst, sizeof(BurstSlice) * (size_t)h->nSlices));
+    k_burst_desc<<<(h->nSlices + 255) / 256, 256, 0, h->stream>>>(h->nSlices, nO, h->dSliceOff, h->dSliceWidth, h->dKOff,
+                                                                   h->dTBase, h->dTMul, h->dExMask, h->dExMaskT,
+                                                                   h->dTags, h->dCols, h->dBurst);
     NG_HIP(hipGetLastError());
   }
   NG_HIP(hipMalloc(&h->dDiagPos, sizeof(long long) * (size_t)std::max(nO, 1)));

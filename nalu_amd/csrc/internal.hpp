@@ -29,6 +29,32 @@ constexpr unsigned TAG_OTHER = 0xFFFFFFFDu; // graph entry that no edge maps to
 constexpr unsigned TAG_MAX_EDGE = 0x7FFFFFF0u;
 constexpr unsigned ORD_IDENTITY = 0xFAC688u;  // entries 0..7 in order, none early
 
+// per-slice descriptor of the burst assembly kernel (finalize, k_burst_desc): everything a wave
+// needs to form the addresses of its rows' loads, in three 64-byte scalar loads issued together
+constexpr int BURST_W = 8;   // widest slice the burst kernel takes
+constexpr int BURST_NE = 6;  // edges per row its bursts take (further edges: tail loop)
+constexpr unsigned BURST_IRR_NONE = 0xFFFFFFFFu, BURST_IRR_MANY = 0xFFFFFFFEu;
+struct BurstRow {           // the edge list of a row (64 bytes)
+  unsigned lane;            // BurstSlice::reg: unused; BurstSlice::irr: lane of the wave's one irregular row,
+                            // BURST_IRR_NONE, or BURST_IRR_MANY (several: they read tags / columns themselves)
+  unsigned kl;              // 4 bits per edge slot e < BURST_NE: the entry index k of the e-th edge entry
+  unsigned info;            // bits 0-3 edge entries of the row, 4-7 entry of the diagonal + 1 (0: none),
+                            // 8-15 entries a SET pass zeroes, 16-23 edge entries beyond the BURST_NE-th
+  unsigned tb[BURST_NE];    // reg: tBase of slot e (tag = tb[e] + row); irr: the tag itself
+  int ko[BURST_NE];         // reg: kOff of slot e (column = row + ko[e]); irr: the column itself
+  unsigned pad;
+};
+struct alignas(64) BurstSlice {
+  BurstRow reg;                  // the slice's regular rows
+  long long off;                 // = sliceOff
+  int w;                         // = sliceWidth
+  unsigned pad0;
+  unsigned long long irrMask[4]; // exMask | exMaskT per wave
+  unsigned pad1[4];
+  BurstRow irr[4];               // per wave
+};
+static_assert(sizeof(BurstRow) == 64 && sizeof(BurstSlice) == 384, "burst descriptor layout");
+
 struct SellView {
   const long long *sliceOff;
   const int *sliceWidth;
@@ -48,6 +74,7 @@ struct SellView {
   // position i < 8 is (ordWord >> 3 i) & 7, bit 24 + i says that a smaller entry follows later
   // ("early": its diagonal / rhs shares wait in a stash so that they are added in CSR order)
   const unsigned *ordWord;
+  const BurstSlice *burst;  // null when some slice is wider than BURST_W
   // export mode only (else null): edgeOwned[e] == 0 marks an edge another rank assembles; the
   // assembly kernels treat its entries as plain graph entries
   const unsigned char *edgeOwned;
@@ -147,11 +174,12 @@ struct nalu_gpu_linsys {
   unsigned *dTags = nullptr;
   long long *dDiagPos = nullptr;  // SELL position of each row's diagonal entry (-1: none)
   int xcdRun = 8;  // slices per XCD run of the row-kernel schedule (NG_XCD_RUN)
-  int asmVariant = 0;  // 0 row kernel (default), 1 entry-parallel (NG_ASM_ENTRIES), 2 ordered (NG_ASM_ORDER)
+  int asmVariant = 0;  // 0 row kernel (default), 1 entry-parallel (NG_ASM_ENTRIES), 2 ordered (NG_ASM_ORDER), 3 burst (NG_ASM_BURST)
   int *dKOff = nullptr;
   unsigned long long *dExMask = nullptr, *dExMaskT = nullptr;
   unsigned *dTBase = nullptr, *dTMul = nullptr;
   unsigned *dOrdWord = nullptr;  // nSlices
+  nalu_gpu::BurstSlice *dBurst = nullptr;   // nSlices (null: maxSliceWidth > BURST_W)
 
   // edges
   int *dEdgeL = nullptr, *dEdgeR = nullptr;
@@ -302,6 +330,7 @@ inline SellView sell_view(const nalu_gpu_linsys *h)
   v.tMul = h->dTMul;
   v.exMaskT = h->dExMaskT;
   v.ordWord = h->dOrdWord;
+  v.burst = h->dBurst;
   v.edgeOwned = h->dEdgeOwned;
   v.nSlices = h->nSlicesOwned;  // the solver's view: owned rows only
   v.nRows = h->nOwned;

@@ -202,6 +202,145 @@ __global__ __launch_bounds__(256) void kmarch(Fields F, int Z, int run, double *
   if (acc == 1.2345e300) out[0] = acc;
 }
 
+// Modes 8 / 9 / 10: the whole skeleton of mode 4 WITH the continuity flux arithmetic (6 edges per
+// row, fp64, one division each, no FMA contraction) -- 8: every load of the row issued before the
+// first flux; 9: one dependent round trip per edge (loads of edge e, then its flux), as the shipped
+// row kernel does; 10: edge e + 1 in flight while edge e is evaluated.
+// ordered loads: a wavefront-scope relaxed atomic load is a plain global_load that neither the IR
+// passes nor the machine scheduler move across other memory operations (kernel-argument loads are
+// 'invariant' otherwise and get sunk to their uses whatever the source order says)
+#define LDO(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
+struct NodeV { double v[NF]; };
+__device__ __forceinline__ NodeV ldnode(const Fields &F, long long c)
+{
+  NodeV a;
+#pragma unroll
+  for (int i = 0; i < NF; ++i) a.v[i] = LDO(F.f[i] + c);
+  return a;
+}
+__device__ __forceinline__ void flux(const NodeV &L, const NodeV &R, const double av[3], double sign, double &diag, double &b, double &offd)
+{
+  double axdx = 0.0, asq = 0.0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double axj = sign * av[j], dxj = R.v[j] - L.v[j] + 1.0;
+    asq += axj * axj + 1.0;
+    axdx += axj * dxj + 1.0;
+  }
+  const double inv = 1.0 / axdx;
+  const double rhoIp = 0.5 * (R.v[10] + L.v[10]);
+  double tm = -0.1 * (R.v[9] - L.v[9]) * asq * inv;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double axj = sign * av[j], dxj = R.v[j] - L.v[j] + 1.0;
+    const double kxj = axj - asq * inv * dxj;
+    const double rhoU = 0.5 * (R.v[10] * R.v[6 + j] + L.v[10] * L.v[6 + j]);
+    const double uj = 0.5 * (R.v[6 + j] + L.v[6 + j]);
+    const double Gj = 0.5 * (R.v[3 + j] + L.v[3 + j]);
+    tm += (0.5 * rhoU + 0.5 * rhoIp * uj + 0.1 * Gj) * axj - 0.1 * kxj * Gj;
+  }
+  const double lf = -asq * inv;
+  diag += -lf;
+  offd = lf;
+  b += -tm / 0.1;
+}
+template <int ARR>
+__global__ __launch_bounds__(256) void kflux(Fields F, int nSlices, double *out, double *big)
+{
+  const int s = xcd_run(blockIdx.x, nSlices, 8);
+  const long long n = (long long)nSlices * 256;
+  const long long row = (long long)s * 256 + threadIdx.x;
+  const long long ds[6] = {-65536, -256, -1, 1, 256, 65536};
+  // edge slot of entry e: + edges are (dir, row), - edges (dir, neighbour row)
+  long long nbr[6], eid[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) {
+    nbr[e] = clampRow(row + ds[e], row, n);
+    const int dir = e < 3 ? 2 - e : e - 3;
+    eid[e] = dir * n + (e < 3 ? nbr[e] : row);
+  }
+  const NodeV own = ldnode(F, row);
+  double diag = 0.0, b = 0.0, offd[6];
+  if (ARR == 8) {
+    NodeV nb[6];
+    double av[6][3];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      if (e != 2 && e != 3) nb[e] = ldnode(F, nbr[e]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) av[e][c] = LDO(F.area[c] + eid[e]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      if (e == 2 || e == 3) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) nb[e].v[i] = e == 2 ? __shfl_up(own.v[i], 1, 64) : __shfl_down(own.v[i], 1, 64);
+      }
+      flux(own, nb[e], av[e], e < 3 ? -1.0 : 1.0, diag, b, offd[e]);
+    }
+  } else if (ARR == 9) {
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      NodeV nb;
+      double av[3];
+      if (e != 2 && e != 3) nb = ldnode(F, nbr[e]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) av[c] = LDO(F.area[c] + eid[e]);
+      if (e == 2 || e == 3) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) nb.v[i] = e == 2 ? __shfl_up(own.v[i], 1, 64) : __shfl_down(own.v[i], 1, 64);
+      }
+      flux(own, nb, av, e < 3 ? -1.0 : 1.0, diag, b, offd[e]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    NodeV nbN, nbC;
+    double avN[3], avC[3];
+    nbC = ldnode(F, nbr[0]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) avC[c] = LDO(F.area[c] + eid[0]);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      if (e + 1 < 6) {
+        if (e + 1 != 2 && e + 1 != 3) nbN = ldnode(F, nbr[e + 1]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) avN[c] = LDO(F.area[c] + eid[e + 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (e == 2 || e == 3) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) nbC.v[i] = e == 2 ? __shfl_up(own.v[i], 1, 64) : __shfl_down(own.v[i], 1, 64);
+      }
+      flux(own, nbC, avC, e < 3 ? -1.0 : 1.0, diag, b, offd[e]);
+      nbC = nbN;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) avC[c] = avN[c];
+    }
+  }
+  const long long base = (long long)s * 256 * 8 + threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) big[base + (e + (e >= 3)) * 256] = offd[e];
+  big[base + 3 * 256] = diag;
+  out[8 + row] = b;
+}
+template <int ARR>
+void runflux(Fields F, int nSlices, double *out, double *big)
+{
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    CK(hipEventRecord(a));
+    kflux<ARR><<<nSlices, 256>>>(F, nSlices, out, big);
+    CK(hipEventRecord(b));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    if (rep >= 2 && ms < best) best = ms;
+  }
+  printf("mode %d (skeleton + flux arithmetic): %.3f ms\n", ARR, best);
+}
+
 template <int MODE>
 void run(Fields F, int nSlices, double *out, double *big, size_t lds)
 {
@@ -241,7 +380,7 @@ int main(int argc, char **argv)
   for (int c = 0; c < 3; ++c) F.area[c] = ar + (long long)c * 3 * n;
   F.area4 = reinterpret_cast<const double4 *>(ar);
   double *out, *big;
-  CK(hipMalloc(&out, 8));
+  CK(hipMalloc(&out, 8 + n * 8 + 64));
   CK(hipMalloc(&big, n * 8 * 8));
   if (mode == 6 && lds < 22528) lds = 22528;
   if (mode == 7) {
@@ -260,6 +399,9 @@ int main(int argc, char **argv)
     printf("mode 7 Z %d run %d: %.3f ms\n", Z, run, best);
     return 0;
   }
+  if (mode == 8) { runflux<8>(F, nSlices, out, big); return 0; }
+  if (mode == 9) { runflux<9>(F, nSlices, out, big); return 0; }
+  if (mode == 10) { runflux<10>(F, nSlices, out, big); return 0; }
   switch (mode) {
     case 0: run<0>(F, nSlices, out, big, lds); break;
     case 1: run<1>(F, nSlices, out, big, lds); break;

@@ -132,13 +132,20 @@ SLOT_CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", ["default", "NG_ASM_BURST"])
 @pytest.mark.parametrize("dims,perturb,min_computed", SLOT_CASES)
-def test_slot_major_assembly_bit_exact(G, torch, oracle, dims, perturb, min_computed):
+def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, perturb, min_computed, variant):
+    """variant NG_ASM_BURST: the opt-in burst row kernel (a row's loads issued together, edge lists
+    from the per-slice descriptor; the two boundary rows of an x-line are a wave's one irregular
+    row, x-lines that straddle slices give waves with several) -- same bits."""
+    if variant != "default":
+        monkeypatch.setenv(variant, "1")
     c = BenchCase(G, oracle, dims, perturb)
     d = c.dev(torch)
     g = c.gpu_system(G)
     li = g.layout_info()
     n = c.S.n_owned
+    assert li["assembly_variant"] == (0 if variant == "default" else 3)
     assert li["rows_computed_tags"] >= min_computed * n, li
     assert li["rows_computed_columns"] >= min_computed * n, li
     if min_computed > 0:  # and the boundary rows of the x-lines are the flagged exceptions

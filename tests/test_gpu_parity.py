@@ -784,13 +784,15 @@ def test_bulk_sum_into_edges_equals_fused_kernel(G, torch, oracle):
     _compare_system(g, ls, exact=True)
 
 
-@pytest.mark.parametrize("variant", ["NG_ASM_ENTRIES", "NG_ASM_ORDER"])
+@pytest.mark.parametrize("variant", ["NG_ASM_ENTRIES", "NG_ASM_ORDER", "NG_ASM_BURST"])
 def test_alternative_assembly_kernels(G, torch, oracle, monkeypatch, variant):
     """The two opt-in variants of the row gather give the oracle's matrix and rhs bit for bit,
     like the default row kernel.  NG_ASM_ENTRIES=1: persistent entry-parallel kernel (one wave per
     matrix entry of 64 rows, ordered sum of the diagonal / rhs shares through LDS).
     NG_ASM_ORDER=1: entries visited out-of-slice neighbours first, shares still added in CSR
-    order through a stash.  Cases: continuity and scalar operators, a perturbed box, a ragged
+    order through a stash.  NG_ASM_BURST=1: a row's loads issued together from per-lane edge lists,
+    neighbours inside the wave through ds_bpermute (slices wider than 8 entries fall back to the
+    default kernel).  Cases: continuity and scalar operators, a perturbed box, a ragged
     sliver, a box whose lines straddle slices, the 27-point element graph (slices wider than 8
     entries) and an unstructured graph (rows of ~20 entries, flagged slices)."""
     monkeypatch.setenv(variant, "1")
