@@ -388,9 +388,8 @@ __global__ __launch_bounds__(SELL_C, ORDERED ? Op::kOrderedWaves : 1) void k_ass
 // entries in CSR order (computed from the slice's tag / column offsets; the irregular rows load
 // their tags and columns); the lists are the order of evaluation, so the diagonal / rhs sums see
 // the same additions in the same order.  Then NB edges at a time: edge data and neighbour nodes
-// of all NB in flight at once, NB fluxes, NB stores.  No LDS and no barrier: a neighbour whose row
-// is held by another lane of the same wave comes from that lane's registers (ds_bpermute), the
-// others from memory.  The row kernel is bound by its ~8 dependent round trips per row with 20
+// of all NB in flight at once, NB fluxes, NB stores.  Neighbours inside the slice come from LDS
+// (the slice's own data, staged behind the first burst's loads), the others from memory.  The row kernel is bound by its ~8 dependent round trips per row with 20
 // waves per CU; this one needs 1-2 with 8-12 waves.
 #ifndef BURST_NB
 #define BURST_NB 6
@@ -408,12 +407,12 @@ __global__ __launch_bounds__(SELL_C, BurstCfg<Op>::WAVES) void k_assemble_rows_b
   constexpr int NF = sizeof(Node) / sizeof(double);
   constexpr int NB = BurstCfg<Op>::NB;
   constexpr int NE = BURST_NE;  // edges per row taken by the bursts; further ones go through the tail loop
+  __shared__ double lds[NF * SELL_C];
   const int slice = sched_slice(A, blockIdx.x);
   const int r = threadIdx.x;
   const int sBase = slice * SELL_C;
   const int row = sBase + r;
   const bool live = row < A.nRows;
-  const int waveRow0 = sBase + (r & ~63);
   // (wave-uniform addresses: three 64-byte scalar loads, issued together with the row's own data)
   const int wv = __builtin_amdgcn_readfirstlane(r >> 6);
   const BurstSlice *const S = A.burst + slice;
@@ -478,44 +477,53 @@ __global__ __launch_bounds__(SELL_C, BurstCfg<Op>::WAVES) void k_assemble_rows_b
   }
   double diag = 0.0, b = 0.0;
   // ---- bursts of NB edges
+  const int nLive = min(SELL_C, A.nRows - sBase);
 #pragma unroll
   for (int e0 = 0; e0 < NE; e0 += NB) {
-    if (__ballot(ne > e0) == 0ULL) break;
+    const bool any = __ballot(ne > e0) != 0ULL;  // (wave-uniform)
     Edge E[NB];
     Node nb[NB];
-    bool inWave[NB];
+    bool inS[NB];
+    if (any) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int e = e0 + i;
-      const bool act = e < ne;
-      // the neighbour's row sits in another lane of this wave: its registers hold the data
-      inWave[i] = act && (unsigned)(cl[e] - waveRow0) < 64u && cl[e] < A.nRows;
-      if (act) {
-        E[i] = Op::load_edge(P, (long long)(eid[e] & 0x7FFFFFFFu));
-        if (!inWave[i]) nb[i] = Op::load(P, cl[e]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int e = e0 + i;
-      if (__ballot(inWave[i]) != 0ULL) {
-        const double *po = reinterpret_cast<const double *>(&own);
-        double *pn = reinterpret_cast<double *>(&nb[i]);
-        const int src = (cl[e] - waveRow0) & 63;
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          const double v = __shfl(po[f], src, 64);
-          pn[f] = inWave[i] ? v : pn[f];
+      for (int i = 0; i < NB; ++i) {
+        const int e = e0 + i;
+        const bool act = e < ne;
+        inS[i] = act && (unsigned)(cl[e] - sBase) < (unsigned)nLive;  // a row of this slice: from LDS
+        if (act) {
+          E[i] = Op::load_edge(P, (long long)(eid[e] & 0x7FFFFFFFu));
+          if (!inS[i]) nb[i] = Op::load(P, cl[e]);
         }
       }
-      if (e < ne) {
-        double lhs[4], rh[2];
-        Op::edge(P, Op::mirrored(E[i], (eid[e] >> 31) != 0), own, nb[i], lhs, rh);
-        diag += lhs[0];
-        b += rh[0];
-        const long long pos = pos0 + (long long)kk[e] * SELL_C;
-        if (SET) A.vals[pos] = lhs[1];
-        else A.vals[pos] += lhs[1];
+    }
+    if (e0 == 0) {
+      // the slice's own nodal data through LDS, behind the loads of the first burst (the barrier
+      // waits for the own data only: the burst stays in flight)
+      if (live) {
+        const double *po = reinterpret_cast<const double *>(&own);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) lds[f * SELL_C + r] = po[f];
+      }
+      __syncthreads();
+    }
+    if (any) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int e = e0 + i;
+        if (e < ne) {
+          if (inS[i]) {
+            double *pn = reinterpret_cast<double *>(&nb[i]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) pn[f] = lds[f * SELL_C + (cl[e] - sBase)];
+          }
+          double lhs[4], rh[2];
+          Op::edge(P, Op::mirrored(E[i], (eid[e] >> 31) != 0), own, nb[i], lhs, rh);
+          diag += lhs[0];
+          b += rh[0];
+          const long long pos = pos0 + (long long)kk[e] * SELL_C;
+          if (SET) A.vals[pos] = lhs[1];
+          else A.vals[pos] += lhs[1];
+        }
       }
     }
   }
