@@ -72,33 +72,53 @@ __device__ __forceinline__ void cg_scal_b(SolverScalars *sc, const double *red, 
 
 enum { EPI_NONE = 0, EPI_CG_A = 1, EPI_CG_B = 2 };
 
-// fixed-order sum of the per-workgroup partials of every slot (one workgroup per slot, or one
-// workgroup for all slots followed by the scalar recurrence that consumes the sums)
+// fixed-order sum of the per-workgroup partials of every slot (one workgroup per NS slots, or one
+// workgroup for all slots followed by the scalar recurrence that consumes the sums).  The NS
+// slots of a workgroup are summed together -- their loads in flight at once, one barrier -- by
+// shuffle trees inside the 16 waves and one more over the 16 wave sums: two dependent steps
+// instead of a ten-level LDS tree per slot (this kernel is pure latency: it sits between the
+// kernels of every Krylov iteration).
 constexpr int RED_T = 1024;
-template <int EPI>
+template <int EPI, int NS>
 __global__ __launch_bounds__(RED_T) void k_reduce_partials(const double *__restrict__ partials,
                                                           int nblocks, int nslots,
                                                           double *__restrict__ out,
                                                           SolverScalars *sc, double *hist)
 {
-  __shared__ double s[RED_T];
-  for (int slot = blockIdx.x; slot < nslots; slot += gridDim.x) {  // epilogues need a grid of 1
-    const double *p = partials + (size_t)slot * MAX_BLOCKS;
-    double v = 0.0;
-    for (int i0 = threadIdx.x; i0 < nblocks; i0 += RED_T * 16) {  // 16 loads in flight, fixed add order
-      double t[16];
+  __shared__ double s[NS][RED_T / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int slot0 = blockIdx.x * NS; slot0 < nslots; slot0 += gridDim.x * NS) {  // epilogues need a grid of 1
+    double v[NS];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) t[u] = (i0 + u * RED_T < nblocks) ? p[i0 + u * RED_T] : 0.0;
+    for (int q = 0; q < NS; ++q) v[q] = 0.0;
+    for (int i0 = threadIdx.x; i0 < nblocks; i0 += RED_T * 8) {  // 8 NS loads in flight, fixed add order
+      double t[NS][8];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v += t[u];
+      for (int q = 0; q < NS; ++q) {
+        const double *p = partials + (size_t)min(slot0 + q, nslots - 1) * MAX_BLOCKS;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[q][u] = (i0 + u * RED_T < nblocks) ? p[i0 + u * RED_T] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[q] += t[q][u];
     }
-    s[threadIdx.x] = v;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      const double t = wave_sum(v[q]);
+      if (lane == 0) s[q][wave] = t;
+    }
     __syncthreads();
-    for (int o = RED_T / 2; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
-      __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        double t = lane < RED_T / 64 ? s[q][lane] : 0.0;
+#pragma unroll
+        for (int o = RED_T / 128; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+        if (lane == 0 && slot0 + q < nslots) out[slot0 + q] = t;
+      }
     }
-    if (threadIdx.x == 0) out[slot] = s[0];
     __syncthreads();
   }
   if (EPI != EPI_NONE && threadIdx.x == 0) {  // thread 0 wrote out[] itself
@@ -116,18 +136,21 @@ __global__ __launch_bounds__(256) void k_prereduce(const double *__restrict__ sr
                                                     const SolverScalars *__restrict__ sc)
 {
   if (sc && sc->done) return;
-  __shared__ double s[256];
+  __shared__ double s[4];
   const int chunk = (n + PRE_WG - 1) / PRE_WG;
   const int i0 = blockIdx.x * chunk, i1 = min(n, i0 + chunk);
   double v = 0.0;
-  for (int i = i0 + threadIdx.x; i < i1; i += 256) v += src[i];
-  s[threadIdx.x] = v;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
-    __syncthreads();
+  for (int i = i0 + threadIdx.x; i < i1; i += 1024) {  // 4 loads in flight
+    double t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = (i + u * 256 < i1) ? src[i + u * 256] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v += t[u];
   }
-  if (threadIdx.x == 0) dst[blockIdx.x] = s[0];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) dst[blockIdx.x] = ((s[0] + s[1]) + s[2]) + s[3];
 }
 
 // slice partials -> at most PRE_WG partials (in place behind the slice partials)
@@ -146,7 +169,7 @@ int prereduce_slices(nalu_gpu_linsys *h, int *count, const double **src, bool us
 int reduce_partials(nalu_gpu_linsys *h, int nslots, int nblocks, int outOffset,
                     const double *src = nullptr)
 {
-  k_reduce_partials<EPI_NONE><<<nslots, RED_T, 0, h->stream>>>(src ? src : h->dPartials, nblocks, nslots,
+  k_reduce_partials<EPI_NONE, 1><<<nslots, RED_T, 0, h->stream>>>(src ? src : h->dPartials, nblocks, nslots,
                                                         h->dReduce + outOffset, nullptr, nullptr);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
@@ -1038,7 +1061,7 @@ int solve_cg(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEve
     if (h->hasComm) {
       NG_TRY(finish_reduction(h, 1, sb, pp));
     } else {
-      k_reduce_partials<EPI_CG_A><<<1, RED_T, 0, h->stream>>>(pp, sb, 1, h->dReduce, h->dScal, nullptr);
+      k_reduce_partials<EPI_CG_A, 1><<<1, RED_T, 0, h->stream>>>(pp, sb, 1, h->dReduce, h->dScal, nullptr);
     }
     k_cg_update<<<vb, 256, 0, h->stream>>>(n, h->dScal, h->dDinv, h->dQ, h->dR, h->dPartials,
                                            h->hasComm ? h->dReduce : nullptr);
@@ -1046,7 +1069,7 @@ int solve_cg(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEve
       NG_TRY(finish_reduction(h, 2, vb));
       k_cg_scal_b<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist);
     } else {
-      k_reduce_partials<EPI_CG_B><<<1, RED_T, 0, h->stream>>>(h->dPartials, vb, 2, h->dReduce,
+      k_reduce_partials<EPI_CG_B, 2><<<1, RED_T, 0, h->stream>>>(h->dPartials, vb, 2, h->dReduce,
                                                             h->dScal, h->dHist);
     }
     if ((it + 1) % M == 0) {  // the next direction overwrites the oldest one of this batch
@@ -1591,7 +1614,7 @@ extern "C" int nalu_gpu_dot_static(int device, void *hip_stream, const double *a
   const hipStream_t st = (hipStream_t)hip_stream;
   const int vb = vec_grid(n);
   k_dot<<<vb, 256, 0, st>>>(n, a_dev, b_dev, scratch);
-  k_reduce_partials<EPI_NONE><<<1, RED_T, 0, st>>>(scratch, vb, 1, out_dev, nullptr, nullptr);
+  k_reduce_partials<EPI_NONE, 1><<<1, RED_T, 0, st>>>(scratch, vb, 1, out_dev, nullptr, nullptr);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
 }
