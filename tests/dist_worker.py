@@ -198,6 +198,54 @@ def gpu_test(rank, world, method, block=False):
     g.close()
 
 
+def config_test(rank, world, kind):
+    """BASELINE configs 3 and 5 at their own sizes, as far as one GPU allows: the 256^3 box split
+    over the ranks (strong256), or two 512 x 512 x 64 slabs of config 5's weak-scaling box (weak512:
+    512^2 halo faces, 16.8 M nodes per rank), through bench.py's own RankSystem (slot-major edges,
+    z-slabs, the step of the benchmark).  The ranks share the one GPU over gloo; the result is
+    compared with the single-rank GPU run of the same box, whose parity with the oracle
+    tests/test_gpu_bench_path.py establishes at 64^3 / 96^3."""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from bench import RankSystem, workload_dims
+    dims = workload_dims(256, world, "weak") if kind == "weak512" else (256, 256, 256)
+    cfg = nalu_amd.LinearSolverConfig(method="cg", preconditioner="jacobi", tolerance=1e-5, max_iterations=50)
+    if kind == "scalar256":  # config 4: scalar transport (upwind, limiter) + mass term, GMRES(50)/Jacobi
+        cfg = nalu_amd.LinearSolverConfig(method="gmres", preconditioner="jacobi", tolerance=1e-5,
+                                          max_iterations=50, kspace=50)
+
+    def run(r, w):
+        R = RankSystem(dims, r, w, "cuda:0", None, "gloo")
+        x = torch.zeros(R.S.n_local, dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        eq = R.scalar_eqsys(cfg, "cuda:0") if kind == "scalar256" else R.continuity_eqsys(cfg)
+        eq.assemble_and_solve(x)
+        g = R.g
+        assert R.comm is None or not R.comm.errors, R.comm.errors
+        v, b = g.matrix_values(), g.rhs()
+        xo = x[:R.S.n_owned].cpu().numpy()
+        out = dict(hist=g.history.copy(), iters=g.linearSolveIterations, lin=g.linearResidual, nonlin=g.nonLinearResidual,
+                   sums=np.array([np.abs(v).sum(), v.sum(), np.abs(b).sum(), b.sum(), float(len(v)),
+                                  np.abs(xo).sum(), (xo * xo).sum()]))
+        g.close()
+        return out
+
+    mine = run(rank, world)
+    sums = torch.as_tensor(mine["sums"])
+    dist.all_reduce(sums)
+    if rank == 0:
+        one = run(0, 1)
+        assert mine["iters"] == one["iters"] and (kind == "scalar256" or one["iters"] == 50)
+        assert np.abs(mine["hist"] - one["hist"]).max() <= 1e-10
+        assert abs(mine["lin"] - one["lin"]) <= 1e-10 and abs(mine["nonlin"] - one["nonlin"]) <= 1e-10 * one["nonlin"]
+        assert sums[4].item() == one["sums"][4]  # same number of matrix entries in the owned rows
+        rel = np.abs(sums.numpy() - one["sums"]) / np.maximum(np.abs(one["sums"]), 1e-300)
+        assert rel[[0, 2]].max() <= 1e-11, rel  # (sums of 1e8 terms in different orders)
+        # the solution: GMRES's 50 Gram-Schmidt steps amplify the rank-count dependent rounding of the
+        # dot products (history still <= 1e-10 above); CG keeps 1e-11
+        assert rel[[5, 6]].max() <= (1e-8 if kind == "scalar256" else 1e-11), rel
+        assert np.abs(sums.numpy() - one["sums"])[[1, 3]].max() <= 1e-11 * one["sums"][0], rel
+
+
 def export_test(rank, world):
     """NALU_GPU_ASSEMBLY_EXPORT_SHARED_ROWS: the reference's scheme (src/TpetraLinearSystem.C:
     1495-1505, 1686-1707) -- every edge / element assembled on ONE rank, contributions to rows of
@@ -320,6 +368,8 @@ def main():
         plan_test(rank, world)
     elif mode == "export":
         export_test(rank, world)
+    elif mode == "config":
+        config_test(rank, world, sys.argv[2])
     elif mode == "plan_block":
         plan_test(rank, world, block=True)
     elif mode == "block":

@@ -83,6 +83,17 @@ def test_native_rccl_callbacks_world_1(method, side_stream):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["strong256", "weak512", "scalar256"])
+def test_baseline_configs_3_4_5_two_ranks_on_one_gpu(kind):
+    """BASELINE config 3 (256^3 Poisson split over the GPUs), the per-GPU geometry of config 5
+    (512 x 512 x 64 slabs, 512^2 halo faces) and config 4 (256^3 scalar transport + GMRES(50)) at
+    full size with two gloo ranks on the one GPU:
+    iteration count, residual history (<= 1e-10), residual norms and matrix / rhs / solution sums
+    equal the single-rank GPU run of the same box."""
+    _launch(2, "config", kind, timeout=900)
+
+
+@pytest.mark.gpu
 def test_bench_multirank_path_rehearsal():
     """bench.py --gpus 2 as the driver launches it, but with two ranks on the one GPU of the
     test box over gloo (NALU_BENCH_BACKEND): partition, halo plan, callbacks, barrier / MAX
