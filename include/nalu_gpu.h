@@ -127,8 +127,12 @@ typedef struct {
   int max_slice_width;
   int64_t rows_computed_columns; /* owned rows whose column indices are computed (SpMV, assembly) */
   int64_t rows_computed_tags;    /* owned rows whose edge ids are computed (row-gather assembly) */
-  int assembly_variant;          /* row-gather kernel variant in force (0 = default) */
+  int assembly_variant;          /* row-gather kernel in force for the continuity operator: 0 row kernel,
+                                    1 entries, 2 ordered, 3 burst, 4 marching (default where it applies) */
   int xcd_run;                   /* slices per XCD run of the row-kernel schedule */
+  int64_t march_runs;            /* runs of slices the marching assembly kernel walks (0: none) */
+  int64_t march_slices;          /* slices in those runs */
+  int march_longest;             /* slices in the longest run */
 } nalu_gpu_layout_info;
 int nalu_gpu_get_layout_info(nalu_gpu_linsys *h, nalu_gpu_layout_info *info);
 

@@ -77,7 +77,8 @@ class CheckInfo(C.Structure):
 class LayoutInfo(C.Structure):
     _fields_ = [("n_slices", C.c_int64), ("sell_slots", C.c_int64), ("max_slice_width", C.c_int),
                 ("rows_computed_columns", C.c_int64), ("rows_computed_tags", C.c_int64),
-                ("assembly_variant", C.c_int), ("xcd_run", C.c_int)]
+                ("assembly_variant", C.c_int), ("xcd_run", C.c_int),
+                ("march_runs", C.c_int64), ("march_slices", C.c_int64), ("march_longest", C.c_int)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)

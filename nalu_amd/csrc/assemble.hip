@@ -400,7 +400,7 @@ template <> struct BurstCfg<ScalOp> { static constexpr int NB = 3, WAVES = 2; };
 
 template <class Op, bool SET>
 __global__ __launch_bounds__(SELL_C, BurstCfg<Op>::WAVES) void k_assemble_rows_burst(SellView A, typename Op::Params P,
-                                                                                 double *__restrict__ rhs)
+                                                                                 double *__restrict__ rhs, int listBase)
 {
   using Node = typename Op::Node;
   using Edge = typename Op::Edge;
@@ -408,7 +408,8 @@ __global__ __launch_bounds__(SELL_C, BurstCfg<Op>::WAVES) void k_assemble_rows_b
   constexpr int NB = BurstCfg<Op>::NB;
   constexpr int NE = BURST_NE;  // edges per row taken by the bursts; further ones go through the tail loop
   __shared__ double lds[NF * SELL_C];
-  const int slice = sched_slice(A, blockIdx.x);
+  // (listBase >= 0: the single-slice runs A.march[listBase ...] that the marching kernel leaves)
+  const int slice = listBase < 0 ? sched_slice(A, blockIdx.x) : A.march[listBase + blockIdx.x].start;
   const int r = threadIdx.x;
   const int sBase = slice * SELL_C;
   const int row = sBase + r;
@@ -556,6 +557,154 @@ __global__ __launch_bounds__(SELL_C, BurstCfg<Op>::WAVES) void k_assemble_rows_b
   }
   if (SET) rhs[row] = b;
   else rhs[row] += b;
+}
+
+// Marching burst row gather (NG_ASM_MARCH=1): a workgroup walks a run of slices whose rows continue
+// each other (MarchSeg: row + rowStep per step; on a lattice the lines above each other) and keeps
+// in registers what two consecutive rows share -- the upper row's node (the lower row's last
+// neighbour becomes the next own row) and the flux of the edge between them, which is evaluated
+// once: its shares for the upper row (lhs[3], lhs[2], rhs[1]) are exactly what that row's own
+// evaluation gives (the mirror invariance of both edge kernels), so the
+// result stays bit-identical to k_assemble_rows.  Per row: 48 instead of 73 eight-byte loads
+// through the L2 -> L1 fabric.  Only slices with the MARCH_NEAR slot pattern (k_march_links): slot 0
+// = the row below (carried), slot 5 = the row above, slots 2, 3 = rows of the slice (LDS), slots
+// 1, 4 = other slices; a wave's irregular row has its edges in the slots of the regular offsets
+// they match.  The edge ids of the next step are read from the tag array one step ahead.  Slices
+// without the pattern are single-slice runs of the burst kernel (second launch).
+// (the scalar operator's 12 + 4 doubles per node / edge spill at 256 registers: 1.69 against 1.51 ms)
+template <class Op> struct MarchCfg { static constexpr bool kDefault = true; };
+template <> struct MarchCfg<ScalOp> { static constexpr bool kDefault = false; };
+
+template <class Op, bool SET>
+__global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_march(SellView A, typename Op::Params P,
+                                                                  double *__restrict__ rhs)
+{
+  using Node = typename Op::Node;
+  using Edge = typename Op::Edge;
+  constexpr int NF = sizeof(Node) / sizeof(double);
+  constexpr int NE = BURST_NE;
+  __shared__ double lds[2][NF * SELL_C];
+  const MarchSeg G = A.march[xcd_run(blockIdx.x, A.nMarchPat, 8)];
+  const int r = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(r >> 6);
+  int sBase = G.start * SELL_C;
+  int row = sBase + r;  // (pattern slices are full: every row is a row of the matrix)
+  const BurstSlice *const S = A.burst + G.start;
+  const BurstRow D = S->reg, X = S->irr[wv];
+  const int w = S->w;
+  const unsigned long long mI = S->irrMask[wv];
+  long long pos0 = S->off + r;
+  Node own = Op::load(P, row);
+  const bool irregular = (mI >> (r & 63)) & 1ULL;  // the wave's one irregular row
+  // its edges, moved to the slots of the regular offsets they have (wave-uniform arithmetic)
+  unsigned xe[NE], xk[NE], xact = 0;
+  {
+    const int rowX = sBase + wv * 64 + (int)(X.lane & 63u), nx = (int)(X.info & 15u);
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      xe[q] = 0;
+      xk[q] = 0;
+#pragma unroll
+      for (int e = 0; e < NE; ++e)
+        if (e < nx && X.ko[e] - rowX == D.ko[q]) {
+          xe[q] = X.tb[e];
+          xk[q] = (X.kl >> (4 * e)) & 15u;
+          xact |= 1u << q;
+        }
+    }
+  }
+  unsigned eid[NE], kk[NE];
+#pragma unroll
+  for (int q = 0; q < NE; ++q) {
+    eid[q] = irregular ? xe[q] : D.tb[q] + (unsigned)row;
+    kk[q] = irregular ? xk[q] : (D.kl >> (4 * q)) & 15u;
+  }
+  const unsigned act = irregular ? xact : (1u << NE) - 1u;
+  const unsigned info = irregular ? X.info : D.info;
+  const int kDiag = (int)((info >> 4) & 15u) - 1;
+  const unsigned zeroMask = (info >> 8) & 255u;
+  // slot 0: its shares are carried from the row below; the first row of a run evaluates them here,
+  // on its own, so that the steps below never hold slot 0's operands
+  double cDiag = 0.0, cOff = 0.0, cRhs = 0.0;
+  if (act & 1u) {
+    double lhs[4], rh[2];
+    Op::edge(P, Op::mirrored(Op::load_edge(P, (long long)(eid[0] & 0x7FFFFFFFu)), (eid[0] >> 31) != 0), own,
+             Op::load(P, row + D.ko[0]), lhs, rh);
+    cDiag = lhs[0]; cOff = lhs[1]; cRhs = rh[0];
+  }
+  for (int t = 0; t < G.len; ++t) {
+    Edge E[NE];
+    Node nb[NE];
+#pragma unroll
+    for (int e = 1; e < NE; ++e) {
+      if ((act >> e) & 1u) {
+        E[e] = Op::load_edge(P, (long long)(eid[e] & 0x7FFFFFFFu));
+        if (!((MARCH_NEAR >> e) & 1u)) nb[e] = Op::load(P, row + D.ko[e]);
+      }
+    }
+    // the next step's edge ids, one step ahead (the tag array holds every entry)
+    unsigned tgN[NE];
+    if (t + 1 < G.len) {
+#pragma unroll
+      for (int e = 1; e < NE; ++e)
+        if ((act >> e) & 1u) tgN[e] = A.tags[pos0 + G.offStep + (long long)kk[e] * SELL_C];
+    }
+    double *const buf = lds[t & 1];
+    {
+      const double *po = reinterpret_cast<const double *>(&own);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) buf[f * SELL_C + r] = po[f];
+    }
+    __syncthreads();
+    double diag = 0.0, b = 0.0;
+    double nDiag = 0.0, nOff = 0.0, nRhs = 0.0;
+    if (act & 1u) {
+      const long long pos = pos0 + (long long)kk[0] * SELL_C;
+      diag += cDiag;
+      b += cRhs;
+      if (SET) A.vals[pos] = cOff;
+      else A.vals[pos] += cOff;
+    }
+#pragma unroll
+    for (int e = 1; e < NE; ++e) {
+      if (!((act >> e) & 1u)) continue;
+      const long long pos = pos0 + (long long)kk[e] * SELL_C;
+      if ((MARCH_NEAR >> e) & 1u) {
+        double *pn = reinterpret_cast<double *>(&nb[e]);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) pn[f] = buf[f * SELL_C + r + D.ko[e]];
+      }
+      double lhs[4], rh[2];
+      Op::edge(P, Op::mirrored(E[e], (eid[e] >> 31) != 0), own, nb[e], lhs, rh);
+      diag += lhs[0];
+      b += rh[0];
+      if (SET) A.vals[pos] = lhs[1];
+      else A.vals[pos] += lhs[1];
+      if (e == NE - 1) { nDiag = lhs[3]; nOff = lhs[2]; nRhs = rh[1]; }
+    }
+    if (SET) {
+      for (int k = 0; k < w; ++k)
+        if ((zeroMask >> k) & 1u) A.vals[pos0 + (long long)k * SELL_C] = 0.0;
+    }
+    if (kDiag >= 0) {
+      const long long pos = pos0 + (long long)kDiag * SELL_C;
+      if (SET) A.vals[pos] = diag;
+      else A.vals[pos] += diag;
+    }
+    if (SET) rhs[row] = b;
+    else rhs[row] += b;
+    // ---- step: the last neighbour is the next row
+    if (t + 1 < G.len) {
+      own = nb[NE - 1];
+      cDiag = nDiag; cOff = nOff; cRhs = nRhs;
+#pragma unroll
+      for (int e = 1; e < NE; ++e)
+        if ((act >> e) & 1u) eid[e] = tgN[e];
+      sBase += G.rowStep;
+      row += G.rowStep;
+      pos0 += G.offStep;
+    }
+  }
 }
 
 // Entry-parallel row gather, persistent: a workgroup of NW waves assembles one QUARTER slice
@@ -763,9 +912,20 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
       int grid = std::max(1, perCu) * std::max(1, cus);
       grid = std::min((grid + 7) / 8 * 8, (nQ + 7) / 8 * 8);
       kern<<<grid, QROWS * 8, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+    } else if ((h->asmVariant == 4 || (MarchCfg<Op>::kDefault && march_by_default(h))) && h->dBurst && h->dMarch &&
+               !h->dEdgeOwned) {
+      const int nPat = h->nMarchPat, nRest = h->nMarch - h->nMarchPat;
+      if (nPat > 0) {
+        if (set) k_assemble_rows_march<Op, true><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+        else k_assemble_rows_march<Op, false><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+      }
+      if (nRest > 0) {
+        if (set) k_assemble_rows_burst<Op, true><<<nRest, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, nPat);
+        else k_assemble_rows_burst<Op, false><<<nRest, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, nPat);
+      }
     } else if (h->asmVariant == 3 && h->dBurst && !h->dEdgeOwned) {
-      if (set) k_assemble_rows_burst<Op, true><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
-      else k_assemble_rows_burst<Op, false><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+      if (set) k_assemble_rows_burst<Op, true><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, -1);
+      else k_assemble_rows_burst<Op, false><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, -1);
     } else if (h->asmVariant == 2) {
       // NG_ASM_ORDER=1: the slice's out-of-slice entries first (k_slice_order).  HBM traffic falls
       // from 7.3 to 4.7 GB per launch at 256^3, but the 18 extra registers cost a wave per SIMD

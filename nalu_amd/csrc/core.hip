@@ -165,7 +165,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dTags); NG_FREE(h->dDiagPos); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
-  NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dBurst); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
+  NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dBurst); NG_FREE(h->dMarch); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   NG_FREE(h->dY); NG_FREE(h->dList); NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf);
   NG_FREE(h->dRecvBuf); NG_FREE(h->dRecvLids); NG_FREE(h->dEdgeOwned); NG_FREE(h->dExpSendRow); NG_FREE(h->dExpRecvRow);
@@ -475,6 +475,86 @@ __global__ void k_burst_desc(int nSlices, int nRows, const long long *sliceOff, 
   out[s] = D;
 }
 
+// marching links: next[s] = the slice whose rows continue the rows of slice s (row + D, D the
+// column offset of the rows' LAST edge, a whole number of slices) when both slices are full, have
+// the same structure (regular rows and every wave's one irregular row), the rows' last edge in s
+// leads to row + D and their first edge in next[s] back to row; -1 otherwise.
+__device__ bool burst_rows_alike(const BurstRow &a, const BurstRow &b, bool regular, int rowA, int rowB)
+{
+  if (a.lane != b.lane || a.kl != b.kl || a.info != b.info) return false;
+  const int ne = (int)(a.info & 15u);
+  for (int e = 0; e < ne && e < BURST_NE; ++e) {
+    const int da = regular ? a.ko[e] : a.ko[e] - rowA, db = regular ? b.ko[e] : b.ko[e] - rowB;
+    if (da != db) return false;
+  }
+  return true;
+}
+
+// does every row of slice s follow the MARCH_NEAR pattern?  (slot e of a regular row: entry e of
+// the slice's list; an irregular row's edge goes to the slot whose regular offset it has)
+__device__ bool march_pattern(const BurstSlice &a, int s, int nRows)
+{
+  const int ne = (int)(a.reg.info & 15u);
+  if (ne != BURST_NE || ((a.reg.info >> 16) & 255u) || (s + 1) * SELL_C > nRows) return false;
+  for (int wv = 0; wv < 4; ++wv) {
+    const BurstRow &x = a.irr[wv];
+    if (x.lane == BURST_IRR_MANY) return false;
+    for (int l = 0; l < 64; ++l) {
+      const int r = wv * 64 + l;
+      if ((a.irrMask[wv] >> l) & 1ULL) {
+        // (the wave's one irregular row) every edge must sit on a regular offset, same near / far
+        const int row = s * SELL_C + r, nx = (int)(x.info & 15u);
+        if (nx > BURST_NE || ((x.info >> 16) & 255u)) return false;
+        for (int e = 0; e < nx; ++e) {
+          int slot = -1;
+          for (int q = 0; q < BURST_NE; ++q)
+            if (x.ko[e] - row == a.reg.ko[q]) slot = q;
+          if (slot < 0) return false;
+          const bool in = (unsigned)(r + a.reg.ko[slot]) < (unsigned)SELL_C;
+          if (in != (((MARCH_NEAR >> slot) & 1u) != 0)) return false;
+        }
+      } else {
+        for (int e = 0; e < BURST_NE; ++e) {
+          const bool in = (unsigned)(r + a.reg.ko[e]) < (unsigned)SELL_C;
+          if (in != (((MARCH_NEAR >> e) & 1u) != 0)) return false;
+        }
+      }
+    }
+  }
+  return true;
+}
+
+__global__ void k_march_links(int nSlices, int nRows, const BurstSlice *B, int *next, long long *offStep, int *pat)
+{
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nSlices) return;
+  next[s] = -1;
+  offStep[s] = 0;
+  const BurstSlice &a = B[s];
+  pat[s] = march_pattern(a, s, nRows) ? 1 : 0;
+  if (!pat[s]) return;
+  const int ne = BURST_NE;
+  const int D = a.reg.ko[ne - 1];
+  if (D <= 0 || D % SELL_C) return;
+  const long long sn = (long long)s + D / SELL_C;
+  if (sn >= nSlices || !march_pattern(B[sn], (int)sn, nRows)) return;
+  const BurstSlice &b = B[sn];
+  if (a.w != b.w || a.reg.ko[0] != -D || !burst_rows_alike(a.reg, b.reg, true, 0, 0)) return;
+  for (int wv = 0; wv < 4; ++wv) {
+    if (a.irrMask[wv] != b.irrMask[wv]) return;
+    const BurstRow &x = a.irr[wv], &y = b.irr[wv];
+    if (x.lane == BURST_IRR_NONE && y.lane == BURST_IRR_NONE) continue;
+    if (x.lane >= 64u) return;
+    const int rowA = s * SELL_C + wv * 64 + (int)x.lane, rowB = rowA + D;
+    const int nx = (int)(x.info & 15u);
+    if (nx < 2) return;
+    if (!burst_rows_alike(x, y, false, rowA, rowB)) return;
+    if (x.ko[nx - 1] != rowA + D || x.ko[0] != rowA - D) return;
+  }
+  next[s] = (int)sn;
+  offStep[s] = b.off - a.off;
+}
+
 // Tag-offset compression (the assembly kernels' counterpart of the column offsets, see
 // finalize): per (slice, k) find (mul, base) with tag = base + mul * row for most rows --
 // (0, DIAG/PAD/OTHER) for the special tags, (1, tag - row) when the caller numbered the edges
@@ -737,6 +817,8 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
   if (const char *e = getenv("NG_ASM_ENTRIES")) h->asmVariant = atoi(e) ? 1 : 0;
   if (const char *e = getenv("NG_ASM_ORDER")) h->asmVariant = atoi(e) ? 2 : h->asmVariant;
   if (const char *e = getenv("NG_ASM_BURST")) h->asmVariant = atoi(e) ? 3 : h->asmVariant;
+  if (const char *e = getenv("NG_ASM_MARCH")) h->asmVariant = atoi(e) ? 4 : h->asmVariant;
+  h->asmExplicit = getenv("NG_ASM_ENTRIES") || getenv("NG_ASM_ORDER") || getenv("NG_ASM_BURST") || getenv("NG_ASM_MARCH");
 
   // edges: SoA copy on the device + per-entry edge tags
   if (h->nEdges > 0) {
@@ -802,6 +884,64 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
     k_burst_desc<<<(h->nSlices + 255) / 256, 256, 0, h->stream>>>(h->nSlices, nO, h->dSliceOff, h->dSliceWidth, h->dKOff,
                                                                    h->dTBase, h->dTMul, h->dExMask, h->dExMaskT,
                                                                    h->dTags, h->dCols, h->dBurst);
+    NG_HIP(hipGetLastError());
+    // runs of slices for the marching kernel: follow the links while step and storage stride stay
+    // the same, at most MARCH_MAX_LEN slices per run; every slice is in exactly one run
+    {
+      int *dNext = nullptr, *dPat = nullptr;
+      long long *dOffStep = nullptr;
+      NG_HIP(hipMalloc(&dNext, sizeof(int) * (size_t)h->nSlices));
+      NG_HIP(hipMalloc(&dPat, sizeof(int) * (size_t)h->nSlices));
+      NG_HIP(hipMalloc(&dOffStep, sizeof(long long) * (size_t)h->nSlices));
+      k_march_links<<<(h->nSlices + 255) / 256, 256, 0, h->stream>>>(h->nSlices, nO, h->dBurst, dNext, dOffStep, dPat);
+      NG_HIP(hipGetLastError());
+      std::vector<int> nxt((size_t)h->nSlices), pat((size_t)h->nSlices);
+      std::vector<long long> ost((size_t)h->nSlices);
+      NG_HIP(hipStreamSynchronize(h->stream));
+      NG_HIP(hipMemcpy(nxt.data(), dNext, sizeof(int) * nxt.size(), hipMemcpyDeviceToHost));
+      NG_HIP(hipMemcpy(pat.data(), dPat, sizeof(int) * pat.size(), hipMemcpyDeviceToHost));
+      NG_HIP(hipMemcpy(ost.data(), dOffStep, sizeof(long long) * ost.size(), hipMemcpyDeviceToHost));
+      (void)hipFree(dNext);
+      (void)hipFree(dPat);
+      (void)hipFree(dOffStep);
+      const int maxLen = getenv("NG_MARCH_LEN") ? std::max(1, atoi(getenv("NG_MARCH_LEN"))) : MARCH_MAX_LEN;
+      std::vector<MarchSeg> segs, others;
+      std::vector<char> seen((size_t)h->nSlices, 0);
+      for (int s0 = 0; s0 < h->nSlices; ++s0) {
+        if (seen[(size_t)s0]) continue;
+        MarchSeg g{s0, 1, 0, 0, 0};
+        seen[(size_t)s0] = 1;
+        if (!pat[(size_t)s0]) {  // not the marching pattern: a run of one slice for the general kernel
+          others.push_back(g);
+          continue;
+        }
+        int cur = s0;
+        while (g.len < maxLen) {
+          const int n1 = nxt[(size_t)cur];
+          if (n1 < 0 || seen[(size_t)n1]) break;
+          const int step = n1 - cur;
+          if (g.len > 1 && (step != g.step || ost[(size_t)cur] != g.offStep)) break;
+          g.step = step;
+          g.rowStep = step * SELL_C;
+          g.offStep = ost[(size_t)cur];
+          ++g.len;
+          seen[(size_t)n1] = 1;
+          cur = n1;
+        }
+        segs.push_back(g);
+      }
+      h->nMarchPat = (int)segs.size();
+      h->marchSlices = 0;
+      h->marchLongest = 0;
+      for (const MarchSeg &g : segs) {
+        h->marchSlices += g.len;
+        h->marchLongest = std::max(h->marchLongest, g.len);
+      }
+      segs.insert(segs.end(), others.begin(), others.end());
+      h->nMarch = (int)segs.size();
+      NG_HIP(hipMalloc(&h->dMarch, sizeof(MarchSeg) * segs.size()));
+      NG_HIP(hipMemcpy(h->dMarch, segs.data(), sizeof(MarchSeg) * segs.size(), hipMemcpyHostToDevice));
+    }
     NG_HIP(hipGetLastError());
   }
   NG_HIP(hipMalloc(&h->dDiagPos, sizeof(long long) * (size_t)std::max(nO, 1)));
@@ -907,7 +1047,10 @@ extern "C" int nalu_gpu_get_layout_info(nalu_gpu_linsys *h, nalu_gpu_layout_info
   info->max_slice_width = h->maxSliceWidth;
   info->rows_computed_columns = cc;
   info->rows_computed_tags = ct;
-  info->assembly_variant = h->asmVariant;
+  info->assembly_variant = march_by_default(h) ? 4 : h->asmVariant;
+  info->march_runs = h->nMarchPat;
+  info->march_slices = h->marchSlices;
+  info->march_longest = h->marchLongest;
   info->xcd_run = h->xcdRun;
   return NALU_GPU_OK;
 }

@@ -55,6 +55,21 @@ struct alignas(64) BurstSlice {
 };
 static_assert(sizeof(BurstRow) == 64 && sizeof(BurstSlice) == 384, "burst descriptor layout");
 
+// a run of slices the marching assembly kernel walks with one workgroup: slice start + t * step,
+// t < len; every slice of a run has the same structure (k_march_links), its rows' first edge is the
+// last edge of the rows `rowStep` below and its SELL storage lies `offStep` entries further on
+struct MarchSeg {
+  int start, len, step, rowStep;
+  long long offStep;
+};
+constexpr int MARCH_MAX_LEN = 16;
+// the slot pattern the marching kernel is specialised for (a slice qualifies when, for every row,
+// the neighbours of the slots in MARCH_NEAR are rows of the slice and those of the other slots are
+// not; an irregular row's edges are placed in the slots of the regular rows' offsets they match):
+// first / last slot = the rows below / above, slots 2 and 3 = neighbours inside the slice (on a
+// lattice: the line's own x neighbours), slots 1 and 4 = other lines
+constexpr unsigned MARCH_NEAR = 0x0Cu;
+
 struct SellView {
   const long long *sliceOff;
   const int *sliceWidth;
@@ -75,6 +90,8 @@ struct SellView {
   // ("early": its diagonal / rhs shares wait in a stash so that they are added in CSR order)
   const unsigned *ordWord;
   const BurstSlice *burst;  // null when some slice is wider than BURST_W
+  const MarchSeg *march;    // runs of slices for the marching kernel, or null: the first nMarchPat of
+  int nMarch, nMarchPat;    // the nMarch runs have the MARCH_NEAR pattern, the others are single slices
   // export mode only (else null): edgeOwned[e] == 0 marks an edge another rank assembles; the
   // assembly kernels treat its entries as plain graph entries
   const unsigned char *edgeOwned;
@@ -174,12 +191,17 @@ struct nalu_gpu_linsys {
   unsigned *dTags = nullptr;
   long long *dDiagPos = nullptr;  // SELL position of each row's diagonal entry (-1: none)
   int xcdRun = 8;  // slices per XCD run of the row-kernel schedule (NG_XCD_RUN)
-  int asmVariant = 0;  // 0 row kernel (default), 1 entry-parallel (NG_ASM_ENTRIES), 2 ordered (NG_ASM_ORDER), 3 burst (NG_ASM_BURST)
+  int asmVariant = 0;  // 0 row kernel (default), 1 entry-parallel (NG_ASM_ENTRIES), 2 ordered (NG_ASM_ORDER), 3 burst (NG_ASM_BURST), 4 marching (NG_ASM_MARCH; also the automatic choice, see assembly_variant_for)
   int *dKOff = nullptr;
   unsigned long long *dExMask = nullptr, *dExMaskT = nullptr;
   unsigned *dTBase = nullptr, *dTMul = nullptr;
   unsigned *dOrdWord = nullptr;  // nSlices
-  nalu_gpu::BurstSlice *dBurst = nullptr;   // nSlices (null: maxSliceWidth > BURST_W)
+  nalu_gpu::BurstSlice *dBurst = nullptr;
+  nalu_gpu::MarchSeg *dMarch = nullptr;  // marching runs that together cover every slice
+  int nMarch = 0, nMarchPat = 0;
+  long long marchSlices = 0;             // slices in the nMarchPat pattern runs
+  int marchLongest = 0;
+  bool asmExplicit = false;              // an NG_ASM_* variable chose the assembly kernel   // nSlices (null: maxSliceWidth > BURST_W)
 
   // edges
   int *dEdgeL = nullptr, *dEdgeR = nullptr;
@@ -331,6 +353,9 @@ inline SellView sell_view(const nalu_gpu_linsys *h)
   v.exMaskT = h->dExMaskT;
   v.ordWord = h->dOrdWord;
   v.burst = h->dBurst;
+  v.march = h->dMarch;
+  v.nMarch = h->nMarch;
+  v.nMarchPat = h->nMarchPat;
   v.edgeOwned = h->dEdgeOwned;
   v.nSlices = h->nSlicesOwned;  // the solver's view: owned rows only
   v.nRows = h->nOwned;
@@ -364,6 +389,14 @@ __device__ __forceinline__ int xcd_run(int b, int n, int G)
 __device__ __forceinline__ int sched_slice(const SellView &A, int b)
 {
   return xcd_run(b, A.nSlices, A.xcdRun);
+}
+
+// the marching kernel is the row-gather kernel of choice when no NG_ASM_* variable says otherwise
+// and at least half of the slices sit in pattern runs (lattice-numbered meshes)
+inline bool march_by_default(const nalu_gpu_linsys *h)
+{
+  return !h->asmExplicit && h->asmVariant == 0 && h->dBurst && h->dMarch && !h->dEdgeOwned &&
+         2 * h->marchSlices >= (long long)h->nSlices;
 }
 
 void timer_begin(nalu_gpu_linsys *h, int which);

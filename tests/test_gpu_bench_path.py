@@ -129,23 +129,32 @@ SLOT_CASES = [
     ((256, 5, 4), 0.125, 0.9),    # ... on a distorted mesh (non-orthogonal correction active)
     ((512, 3, 3), 0.125, 0.9),    # two slices per x-line (the 512^3 geometry)
     ((300, 4, 3), 0.0, 0.0),      # x-lines straddle slices: mixed flagged / computed rows
+    ((256, 6, 20), 0.125, 0.9),   # long z-runs for the marching kernel (carried edge over 16 steps)
 ]
 
 
-@pytest.mark.parametrize("variant", ["default", "NG_ASM_BURST"])
+@pytest.mark.parametrize("variant", ["default", "row", "NG_ASM_BURST", "NG_ASM_MARCH"])
 @pytest.mark.parametrize("dims,perturb,min_computed", SLOT_CASES)
 def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, perturb, min_computed, variant):
-    """variant NG_ASM_BURST: the opt-in burst row kernel (a row's loads issued together, edge lists
+    """default: the automatic choice (the marching kernel where at least half of the slices are in
+    pattern runs, else the row kernel); row: the plain row kernel; NG_ASM_MARCH: marching + burst
+    kernels forced.  variant NG_ASM_BURST: the opt-in burst row kernel (a row's loads issued together, edge lists
     from the per-slice descriptor; the two boundary rows of an x-line are a wave's one irregular
     row, x-lines that straddle slices give waves with several) -- same bits."""
-    if variant != "default":
+    if variant == "row":  # the plain row kernel, which the automatic choice replaces on lattices
+        monkeypatch.setenv("NG_ASM_MARCH", "0")
+    elif variant != "default":
         monkeypatch.setenv(variant, "1")
     c = BenchCase(G, oracle, dims, perturb)
     d = c.dev(torch)
     g = c.gpu_system(G)
     li = g.layout_info()
     n = c.S.n_owned
-    assert li["assembly_variant"] == (0 if variant == "default" else 3)
+    marching = li["march_slices"] * 2 >= li["n_slices"]  # what makes the marching kernel the automatic choice
+    assert li["assembly_variant"] == {"default": 4 if marching else 0, "row": 0, "NG_ASM_BURST": 3,
+                                      "NG_ASM_MARCH": 4}[variant]
+    if dims == (256, 6, 20):  # 4 interior lines x 18 interior planes: runs of 16 + 2 slices
+        assert marching and li["march_longest"] == 16 and li["march_slices"] == 72 and li["march_runs"] == 8, li
     assert li["rows_computed_tags"] >= min_computed * n, li
     assert li["rows_computed_columns"] >= min_computed * n, li
     if min_computed > 0:  # and the boundary rows of the x-lines are the flagged exceptions

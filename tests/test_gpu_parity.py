@@ -784,7 +784,7 @@ def test_bulk_sum_into_edges_equals_fused_kernel(G, torch, oracle):
     _compare_system(g, ls, exact=True)
 
 
-@pytest.mark.parametrize("variant", ["NG_ASM_ENTRIES", "NG_ASM_ORDER", "NG_ASM_BURST"])
+@pytest.mark.parametrize("variant", ["NG_ASM_ENTRIES", "NG_ASM_ORDER", "NG_ASM_BURST", "NG_ASM_MARCH"])
 def test_alternative_assembly_kernels(G, torch, oracle, monkeypatch, variant):
     """The two opt-in variants of the row gather give the oracle's matrix and rhs bit for bit,
     like the default row kernel.  NG_ASM_ENTRIES=1: persistent entry-parallel kernel (one wave per
