@@ -584,7 +584,7 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_march(SellView A, t
   constexpr int NF = sizeof(Node) / sizeof(double);
   constexpr int NE = BURST_NE;
   __shared__ double lds[2][NF * SELL_C];
-  const MarchSeg G = A.march[xcd_run(blockIdx.x, A.nMarchPat, 8)];
+  const MarchSeg G = A.march[xcd_run(blockIdx.x, A.nMarchPat, A.marchXcdRun)];
   const int r = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(r >> 6);
   int sBase = G.start * SELL_C;

@@ -931,6 +931,7 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
         segs.push_back(g);
       }
       h->nMarchPat = (int)segs.size();
+      if (const char *e = getenv("NG_MARCH_XCD")) h->marchXcdRun = std::max(1, atoi(e));
       h->marchSlices = 0;
       h->marchLongest = 0;
       for (const MarchSeg &g : segs) {

@@ -92,6 +92,7 @@ struct SellView {
   const BurstSlice *burst;  // null when some slice is wider than BURST_W
   const MarchSeg *march;    // runs of slices for the marching kernel, or null: the first nMarchPat of
   int nMarch, nMarchPat;    // the nMarch runs have the MARCH_NEAR pattern, the others are single slices
+  int marchXcdRun;          // consecutive runs per XCD in the marching kernel's schedule
   // export mode only (else null): edgeOwned[e] == 0 marks an edge another rank assembles; the
   // assembly kernels treat its entries as plain graph entries
   const unsigned char *edgeOwned;
@@ -201,6 +202,7 @@ struct nalu_gpu_linsys {
   int nMarch = 0, nMarchPat = 0;
   long long marchSlices = 0;             // slices in the nMarchPat pattern runs
   int marchLongest = 0;
+  int marchXcdRun = 8;
   bool asmExplicit = false;              // an NG_ASM_* variable chose the assembly kernel   // nSlices (null: maxSliceWidth > BURST_W)
 
   // edges
@@ -356,6 +358,7 @@ inline SellView sell_view(const nalu_gpu_linsys *h)
   v.march = h->dMarch;
   v.nMarch = h->nMarch;
   v.nMarchPat = h->nMarchPat;
+  v.marchXcdRun = h->marchXcdRun;
   v.edgeOwned = h->dEdgeOwned;
   v.nSlices = h->nSlicesOwned;  // the solver's view: owned rows only
   v.nRows = h->nOwned;
