@@ -417,6 +417,11 @@ def main():
         else:
             wl = (f"Hex8 box {nx}x{ny}x{nz} nodes, {n}^3 = {Nl} nodes per GPU as z-slabs of {nz // world} "
                   f"element layers (N = 8: the 512^3 box of config 5): ")
+        op = "ContOp" if a.workload == "continuity" else "ScalOp"
+        asm_kernel = f"k_assemble_rows<{op}> ({a.mode})"
+        if a.mode == "rows" and a.workload == "continuity" and layout["assembly_variant"] == 4:
+            asm_kernel = (f"k_assemble_rows_march<{op}> over {layout['march_runs']} runs of slices "
+                          f"({layout['march_slices']} of {layout['n_slices']} slices) + k_assemble_rows_burst for the rest")
         env_knobs = {k: v for k, v in os.environ.items() if k.startswith("NG_") or k in ("NALU_EDGE_ORDER",)}
         out = {
             "metric": "edges assembled/s + SpMV GB/s (% HBM peak), Hex8 256^3 Poisson, 1-8 GPUs",
@@ -440,7 +445,7 @@ def main():
                          "frac": spmv_bytes / spmv_t / 1e9 / HBM_PEAK_GBS,
                          "traffic": pmc.get("k_spmv", {}).get("hbm_bytes") if a.workload == "continuity" else None,
                          "algorithmic_bytes": spmv_bytes, "avg_ms": spmv_t * 1e3, "launches": spmv_cnt},
-            "roofline_assembly": {"kernel": f"k_assemble_rows<{'ContOp' if a.workload == 'continuity' else 'ScalOp'}> ({a.mode})", "bound": "hbm",
+            "roofline_assembly": {"kernel": asm_kernel, "bound": "hbm",
                                   "achieved": asm_bytes / asm_t / 1e9, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": asm_bytes / asm_t / 1e9 / HBM_PEAK_GBS,
                                   "traffic": pmc.get("k_assemble_rows", {}).get("hbm_bytes") if a.workload == "continuity" else None,

@@ -9,4 +9,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 cd $R
 bash scripts/pmc_short.sh r2asm scripts/pmc_asm.py 256
 python scripts/pmc_summary.py gpurun_out/pmc_r2asm > gpurun_out/r2_pmc_summary.txt
+python scripts/r2_traffic.py gpurun_out/pmc_r2asm > gpurun_out/r2_traffic.json
+# the plain row kernel for comparison
+NG_ASM_MARCH=0 bash scripts/pmc_short.sh r2asm_row scripts/pmc_asm.py 256
+python scripts/pmc_summary.py gpurun_out/pmc_r2asm_row > gpurun_out/r2_pmc_summary_row_kernel.txt
 tail -n 3 gpurun_out/r2_bench.json
