@@ -394,12 +394,13 @@ __device__ __forceinline__ int sched_slice(const SellView &A, int b)
   return xcd_run(b, A.nSlices, A.xcdRun);
 }
 
-// the marching kernel is the row-gather kernel of choice when no NG_ASM_* variable says otherwise
-// and at least half of the slices sit in pattern runs (lattice-numbered meshes)
+// the marching kernel is the row-gather kernel of choice when no NG_ASM_* variable says otherwise,
+// at least half of the slices sit in pattern runs (lattice-numbered meshes) and the runs average
+// four slices or more (a run's first and last rows pay an extra round trip each)
 inline bool march_by_default(const nalu_gpu_linsys *h)
 {
   return !h->asmExplicit && h->asmVariant == 0 && h->dBurst && h->dMarch && !h->dEdgeOwned &&
-         2 * h->marchSlices >= (long long)h->nSlices;
+         2 * h->marchSlices >= (long long)h->nSlices && h->marchSlices >= 4LL * h->nMarchPat;
 }
 
 void timer_begin(nalu_gpu_linsys *h, int which);

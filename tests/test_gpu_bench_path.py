@@ -150,7 +150,8 @@ def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, pert
     g = c.gpu_system(G)
     li = g.layout_info()
     n = c.S.n_owned
-    marching = li["march_slices"] * 2 >= li["n_slices"]  # what makes the marching kernel the automatic choice
+    # what makes the marching kernel the automatic choice
+    marching = li["march_slices"] * 2 >= li["n_slices"] and li["march_slices"] >= 4 * li["march_runs"]
     assert li["assembly_variant"] == {"default": 4 if marching else 0, "row": 0, "NG_ASM_BURST": 3,
                                       "NG_ASM_MARCH": 4}[variant]
     if dims == (256, 6, 20):  # 4 interior lines x 18 interior planes: runs of 16 + 2 slices
