@@ -173,6 +173,13 @@ def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, pert
                                 d["mdot"], **opts)
         g.loadComplete()
         _equal_system(g, c.oracle_scalar(**opts))
+    # a second assembly on top of the first one (the kernels' accumulate path): exactly twice the values
+    g.zeroSystem()
+    for _ in range(2):
+        g.assemble_continuity_edges(d["coords"], d["dpdx"], d["vel"], d["p"], d["rho"], d["area"], c.dt)
+    g.loadComplete()
+    ls = c.oracle_continuity()
+    assert np.array_equal(g.matrix_values(), 2.0 * ls.owned_csr()[2]) and np.array_equal(g.rhs(), 2.0 * ls.owned_rhs())
     # the adjacent edge algorithms on slot-major edges
     mdot = torch.empty(c.S.n_edges, dtype=torch.float64, device="cuda:0")
     g.compute_mdot_edges(d["coords"], d["dpdx"], d["vel"], d["p"], d["rho"], d["area"], c.dt, mdot)
