@@ -583,7 +583,8 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_march(SellView A, t
   using Edge = typename Op::Edge;
   constexpr int NF = sizeof(Node) / sizeof(double);
   constexpr int NE = BURST_NE;
-  __shared__ double lds[2][NF * SELL_C];
+  constexpr int LW = SELL_C + 2;  // the slice's rows and the node just below / above them
+  __shared__ double lds[2][NF * LW];
   const MarchSeg G = A.march[xcd_run(blockIdx.x, A.nMarchPat, A.marchXcdRun)];
   const int r = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(r >> 6);
@@ -595,6 +596,12 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_march(SellView A, t
   const unsigned long long mI = S->irrMask[wv];
   long long pos0 = S->off + r;
   Node own = Op::load(P, row);
+  // the node just below the slice (lane 0) / just above it (last lane), when some row reads it
+  // through a near slot; like the own row it is loaded one step ahead
+  const bool haloLane = (r == 0 && (G.halo & 1)) || (r == SELL_C - 1 && (G.halo & 2));
+  const int haloOff = r == 0 ? -1 : 1;
+  Node hal;
+  if (haloLane) hal = Op::load(P, row + haloOff);
   const bool irregular = (mI >> (r & 63)) & 1ULL;  // the wave's one irregular row
   // its edges, moved to the slots of the regular offsets they have (wave-uniform arithmetic)
   unsigned xe[NE], xk[NE], xact = 0;
@@ -653,7 +660,13 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_march(SellView A, t
     {
       const double *po = reinterpret_cast<const double *>(&own);
 #pragma unroll
-      for (int f = 0; f < NF; ++f) buf[f * SELL_C + r] = po[f];
+      for (int f = 0; f < NF; ++f) buf[f * LW + r + 1] = po[f];
+      if (haloLane) {
+        const double *ph = reinterpret_cast<const double *>(&hal);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) buf[f * LW + r + 1 + haloOff] = ph[f];
+        if (t + 1 < G.len) hal = Op::load(P, row + G.rowStep + haloOff);  // (the next step's)
+      }
     }
     __syncthreads();
     double diag = 0.0, b = 0.0;
@@ -672,7 +685,7 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_march(SellView A, t
       if ((MARCH_NEAR >> e) & 1u) {
         double *pn = reinterpret_cast<double *>(&nb[e]);
 #pragma unroll
-        for (int f = 0; f < NF; ++f) pn[f] = buf[f * SELL_C + r + D.ko[e]];
+        for (int f = 0; f < NF; ++f) pn[f] = buf[f * LW + r + 1 + D.ko[e]];
       }
       double lhs[4], rh[2];
       Op::edge(P, Op::mirrored(E[e], (eid[e] >> 31) != 0), own, nb[e], lhs, rh);

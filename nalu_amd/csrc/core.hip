@@ -491,37 +491,47 @@ __device__ bool burst_rows_alike(const BurstRow &a, const BurstRow &b, bool regu
 }
 
 // does every row of slice s follow the MARCH_NEAR pattern?  (slot e of a regular row: entry e of
-// the slice's list; an irregular row's edge goes to the slot whose regular offset it has)
-__device__ bool march_pattern(const BurstSlice &a, int s, int nRows)
+// the slice's list; an irregular row's edge goes to the slot whose regular offset it has.)  The
+// neighbours of the near slots must be rows of the slice or the node just below / above it.
+// Returns 0 (no) or 1 | 2 (the node below is read) | 4 (the node above is read).
+__device__ int march_pattern(const BurstSlice &a, int s, int nRows)
 {
   const int ne = (int)(a.reg.info & 15u);
-  if (ne != BURST_NE || ((a.reg.info >> 16) & 255u) || (s + 1) * SELL_C > nRows) return false;
+  if (ne != BURST_NE || ((a.reg.info >> 16) & 255u) || (s + 1) * SELL_C > nRows) return 0;
+  int code = 1;
   for (int wv = 0; wv < 4; ++wv) {
     const BurstRow &x = a.irr[wv];
-    if (x.lane == BURST_IRR_MANY) return false;
+    if (x.lane == BURST_IRR_MANY) return 0;
     for (int l = 0; l < 64; ++l) {
       const int r = wv * 64 + l;
       if ((a.irrMask[wv] >> l) & 1ULL) {
-        // (the wave's one irregular row) every edge must sit on a regular offset, same near / far
+        // (the wave's one irregular row) every edge must sit on a regular offset
         const int row = s * SELL_C + r, nx = (int)(x.info & 15u);
-        if (nx > BURST_NE || ((x.info >> 16) & 255u)) return false;
+        if (nx > BURST_NE || ((x.info >> 16) & 255u)) return 0;
         for (int e = 0; e < nx; ++e) {
           int slot = -1;
           for (int q = 0; q < BURST_NE; ++q)
             if (x.ko[e] - row == a.reg.ko[q]) slot = q;
-          if (slot < 0) return false;
-          const bool in = (unsigned)(r + a.reg.ko[slot]) < (unsigned)SELL_C;
-          if (in != (((MARCH_NEAR >> slot) & 1u) != 0)) return false;
+          if (slot < 0) return 0;
+          if ((MARCH_NEAR >> slot) & 1u) {
+            const int idx = r + a.reg.ko[slot];
+            if (idx < -1 || idx > SELL_C) return 0;
+            if (idx == -1) code |= 2;
+            if (idx == SELL_C) code |= 4;
+          }
         }
       } else {
         for (int e = 0; e < BURST_NE; ++e) {
-          const bool in = (unsigned)(r + a.reg.ko[e]) < (unsigned)SELL_C;
-          if (in != (((MARCH_NEAR >> e) & 1u) != 0)) return false;
+          if (!((MARCH_NEAR >> e) & 1u)) continue;
+          const int idx = r + a.reg.ko[e];
+          if (idx < -1 || idx > SELL_C) return 0;
+          if (idx == -1) code |= 2;
+          if (idx == SELL_C) code |= 4;
         }
       }
     }
   }
-  return true;
+  return code;
 }
 
 __global__ void k_march_links(int nSlices, int nRows, const BurstSlice *B, int *next, long long *offStep, int *pat)
@@ -531,13 +541,13 @@ __global__ void k_march_links(int nSlices, int nRows, const BurstSlice *B, int *
   next[s] = -1;
   offStep[s] = 0;
   const BurstSlice &a = B[s];
-  pat[s] = march_pattern(a, s, nRows) ? 1 : 0;
+  pat[s] = march_pattern(a, s, nRows);
   if (!pat[s]) return;
   const int ne = BURST_NE;
   const int D = a.reg.ko[ne - 1];
   if (D <= 0 || D % SELL_C) return;
   const long long sn = (long long)s + D / SELL_C;
-  if (sn >= nSlices || !march_pattern(B[sn], (int)sn, nRows)) return;
+  if (sn >= nSlices || march_pattern(B[sn], (int)sn, nRows) != pat[s]) return;
   const BurstSlice &b = B[sn];
   if (a.w != b.w || a.reg.ko[0] != -D || !burst_rows_alike(a.reg, b.reg, true, 0, 0)) return;
   for (int wv = 0; wv < 4; ++wv) {
@@ -909,7 +919,7 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
       std::vector<char> seen((size_t)h->nSlices, 0);
       for (int s0 = 0; s0 < h->nSlices; ++s0) {
         if (seen[(size_t)s0]) continue;
-        MarchSeg g{s0, 1, 0, 0, 0};
+        MarchSeg g{s0, 1, 0, 0, 0, pat[(size_t)s0] >> 1, 0};
         seen[(size_t)s0] = 1;
         if (!pat[(size_t)s0]) {  // not the marching pattern: a run of one slice for the general kernel
           others.push_back(g);

@@ -61,13 +61,16 @@ static_assert(sizeof(BurstRow) == 64 && sizeof(BurstSlice) == 384, "burst descri
 struct MarchSeg {
   int start, len, step, rowStep;
   long long offStep;
+  int halo, pad;  // bit 0 / 1: some row reads the node just below / above the slice through a near slot
 };
 constexpr int MARCH_MAX_LEN = 16;
 // the slot pattern the marching kernel is specialised for (a slice qualifies when, for every row,
 // the neighbours of the slots in MARCH_NEAR are rows of the slice and those of the other slots are
 // not; an irregular row's edges are placed in the slots of the regular rows' offsets they match):
 // first / last slot = the rows below / above, slots 2 and 3 = neighbours inside the slice (on a
-// lattice: the line's own x neighbours), slots 1 and 4 = other lines
+// lattice: the line's own x neighbours; "inside" includes the node just below and just above the
+// slice, which the kernel stages next to the slice's own data -- a 512-node line is two slices),
+// slots 1 and 4 = anything
 constexpr unsigned MARCH_NEAR = 0x0Cu;
 
 struct SellView {

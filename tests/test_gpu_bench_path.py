@@ -130,6 +130,7 @@ SLOT_CASES = [
     ((512, 3, 3), 0.125, 0.9),    # two slices per x-line (the 512^3 geometry)
     ((300, 4, 3), 0.0, 0.0),      # x-lines straddle slices: mixed flagged / computed rows
     ((256, 6, 20), 0.125, 0.9),   # long z-runs for the marching kernel (carried edge over 16 steps)
+    ((512, 6, 20), 0.125, 0.9),   # ... with two slices per x-line: the node across the slice boundary is staged too
 ]
 
 
@@ -156,6 +157,8 @@ def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, pert
                                       "NG_ASM_MARCH": 4}[variant]
     if dims == (256, 6, 20):  # 4 interior lines x 18 interior planes: runs of 16 + 2 slices
         assert marching and li["march_longest"] == 16 and li["march_slices"] == 72 and li["march_runs"] == 8, li
+    if dims == (512, 6, 20):  # ... two slices per line
+        assert marching and li["march_longest"] == 16 and li["march_slices"] == 144 and li["march_runs"] == 16, li
     assert li["rows_computed_tags"] >= min_computed * n, li
     assert li["rows_computed_columns"] >= min_computed * n, li
     if min_computed > 0:  # and the boundary rows of the x-lines are the flagged exceptions
