@@ -451,7 +451,7 @@ __global__ void k_burst_desc(int nSlices, int nRows, const long long *sliceOff, 
       while (!((m >> lane) & 1ULL)) ++lane;
       R.lane = (unsigned)lane;
       const long long p0 = off + wv * 64 + lane;
-      unsigned ne = 0, kd = 0, zm = 0, lm = 0;
+      unsigned ne = 0, kd = 0, zm = 0, lm = 0, other = 0;
       for (int k = 0; k < w && k < BURST_W; ++k) {
         const unsigned tag = tags[p0 + (long long)k * SELL_C];
         if (tag < TAG_OTHER) {
@@ -467,9 +467,11 @@ __global__ void k_burst_desc(int nSlices, int nRows, const long long *sliceOff, 
           kd = (unsigned)k + 1;
         } else {
           zm |= 1u << k;
+          if (tag == TAG_OTHER) other = 1u << 24;
         }
       }
       burst_row_finish(R, ne, kd, zm, lm);
+      R.info |= other;
     }
   }
   out[s] = D;

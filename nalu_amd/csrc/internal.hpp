@@ -39,7 +39,9 @@ struct BurstRow {           // the edge list of a row (64 bytes)
                             // BURST_IRR_NONE, or BURST_IRR_MANY (several: they read tags / columns themselves)
   unsigned kl;              // 4 bits per edge slot e < BURST_NE: the entry index k of the e-th edge entry
   unsigned info;            // bits 0-3 edge entries of the row, 4-7 entry of the diagonal + 1 (0: none),
-                            // 8-15 entries a SET pass zeroes, 16-23 edge entries beyond the BURST_NE-th
+                            // 8-15 entries a SET pass zeroes, 16-23 edge entries beyond the BURST_NE-th,
+                            // bit 24: the row has graph entries that are neither edges nor the diagonal nor
+                            // padding (their columns are not in this list)
   unsigned tb[BURST_NE];    // reg: tBase of slot e (tag = tb[e] + row); irr: the tag itself
   int ko[BURST_NE];         // reg: kOff of slot e (column = row + ko[e]); irr: the column itself
   unsigned pad;

@@ -279,10 +279,51 @@ __global__ __launch_bounds__(SELL_C) void k_spmv(SellView A, const double *__res
   const int s = list ? list[xcd_run(blockIdx.x, nList, run)] : xcd_run(blockIdx.x, A.nSlices, run);
   const int row = s * SELL_C + threadIdx.x;
   const long long so = A.sliceOff[s];
-  const unsigned long long mask = A.exMask[(size_t)s * 4 + (threadIdx.x >> 6)];  // wave-uniform
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned long long mask = A.exMask[(size_t)s * 4 + wave];  // wave-uniform
   const bool ex = (mask >> (threadIdx.x & 63)) & 1ULL;
-  const double sum = row_sum<DINV>(A, so + threadIdx.x, A.sliceWidth[s], A.kOff + so / SELL_C, ex, row,
-                                   x, dinv);
+  double sum;
+  // A wave whose only row with irregular columns is described by the assembly's per-slice descriptor
+  // (BurstSlice::irr: on a lattice the first / last node of an x-line) takes that row's columns from
+  // the descriptor -- a scalar load issued with the slice offset -- instead of reading them from the
+  // column array, which is a dependent round trip that the whole wave waits for (two of the four
+  // waves of every slice at 256^3: 0.270 -> 0.2xx ms).
+  const BurstRow *X = (A.burst && mask != 0ULL) ? &A.burst[s].irr[wave] : nullptr;
+  // (not for a row with more than BURST_NE edges or with other graph entries: bits 16-24 of info)
+  if (X && X->lane < 64u && (X->info >> 16) == 0u && mask == (1ULL << X->lane)) {
+    constexpr int WMAX = BURST_W;
+    const int w = A.sliceWidth[s];
+    const int *off = A.kOff + so / SELL_C;
+    const long long pos = so + threadIdx.x;
+    const unsigned kl = X->kl, nx = X->info & 15u;
+    int c[WMAX];
+    double v[WMAX], xv[WMAX];
+#pragma unroll
+    for (int j = 0; j < WMAX; ++j) c[j] = j < w ? row + off[j] : row;
+    if (ex) {  // (one lane) the diagonal and the padding have the row's own column, the edges are listed
+#pragma unroll
+      for (int j = 0; j < WMAX; ++j) c[j] = row;
+#pragma unroll
+      for (int e = 0; e < BURST_NE; ++e) {
+        const unsigned k = (kl >> (4 * e)) & 15u;
+#pragma unroll
+        for (int j = 0; j < WMAX; ++j)
+          if ((unsigned)e < nx && k == (unsigned)j) c[j] = X->ko[e];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WMAX; ++j)
+      if (j < w) v[j] = __builtin_nontemporal_load(A.vals + pos + (long long)j * SELL_C);
+#pragma unroll
+    for (int j = 0; j < WMAX; ++j)
+      if (j < w) xv[j] = DINV ? dinv[c[j]] * x[c[j]] : x[c[j]];
+    sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < WMAX; ++j)
+      if (j < w) sum += v[j] * xv[j];
+  } else {
+    sum = row_sum<DINV>(A, so + threadIdx.x, A.sliceWidth[s], A.kOff + so / SELL_C, ex, row, x, dinv);
+  }
   if (stop) return;
   double prod = 0.0;
   if (row < A.nRows) {
