@@ -269,6 +269,18 @@ __global__ __launch_bounds__(SELL_C, ORDERED ? Op::kOrderedWaves : 1) void k_ass
   const bool ex = (A.exMask[(size_t)slice * 4 + (r >> 6)] >> (r & 63)) & 1ULL;
   const unsigned *tBase = A.tBase + off / SELL_C, *tMul = A.tMul + off / SELL_C;
   const bool exT = (A.exMaskT[(size_t)slice * 4 + (r >> 6)] >> (r & 63)) & 1ULL;
+  // A wave whose only irregular row is described by the slice descriptor (BurstSlice::irr: on a
+  // lattice the first / last node of an x-line) takes that row's tags and columns from the
+  // descriptor (scalar registers) instead of loading them entry by entry: two dependent round trips
+  // less per entry for the whole wave.
+  const int wv = __builtin_amdgcn_readfirstlane(r >> 6);
+  const BurstRow *X = nullptr;
+  if (!ORDERED && A.burst) {
+    const BurstRow *cand = &A.burst[slice].irr[wv];
+    if (cand->lane < 64u && (cand->info >> 16) == 0u) X = cand;  // (one such row, no edges or entries off the list)
+  }
+  const bool useX = X != nullptr;
+  const bool isXLane = useX && (unsigned)(r & 63) == X->lane;
   double diag = 0.0, b = 0.0;
   long long diagPos = -1;
   if (ORDERED) {
@@ -344,13 +356,29 @@ __global__ __launch_bounds__(SELL_C, ORDERED ? Op::kOrderedWaves : 1) void k_ass
   } else {
     for (int k = 0; k < w; ++k) {
       const long long pos = off + (long long)k * SELL_C + r;
-      const unsigned tag = exT ? A.tags[pos] : tBase[k] + tMul[k] * (unsigned)row;
+      unsigned tag;
+      int c;
+      if (useX) {
+        // (wave-uniform) entry k of the irregular row: an edge of its list, the diagonal, or padding
+        unsigned tagX = ((int)((X->info >> 4) & 15u) - 1 == k) ? TAG_DIAG : TAG_PAD;
+        int colX = row;
+#pragma unroll
+        for (int e = 0; e < BURST_NE; ++e)
+          if ((unsigned)e < (X->info & 15u) && ((X->kl >> (4 * e)) & 15u) == (unsigned)k) {
+            tagX = X->tb[e];
+            colX = X->ko[e];
+          }
+        tag = isXLane ? tagX : tBase[k] + tMul[k] * (unsigned)row;
+        c = isXLane ? colX : row + kOff[k];
+      } else {
+        tag = exT ? A.tags[pos] : tBase[k] + tMul[k] * (unsigned)row;
+        c = ex ? A.cols[pos] : row + kOff[k];
+      }
       if (tag >= TAG_OTHER || (A.edgeOwned && !A.edgeOwned[tag & 0x7FFFFFFFu])) {
         if (tag == TAG_DIAG) diagPos = pos;
         else if (SET) A.vals[pos] = 0.0;  // (an edge another rank assembles counts as no edge)
         continue;
       }
-      const int c = ex ? A.cols[pos] : row + kOff[k];
       const long long e = tag & 0x7FFFFFFFu;
       const bool isR = (tag >> 31) != 0;
       Node nb;
