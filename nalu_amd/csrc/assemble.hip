@@ -417,13 +417,12 @@ __global__ __launch_bounds__(SELL_C, ORDERED ? Op::kOrderedWaves : 1) void k_ass
 // their tags and columns); the lists are the order of evaluation, so the diagonal / rhs sums see
 // the same additions in the same order.  Then NB edges at a time: edge data and neighbour nodes
 // of all NB in flight at once, NB fluxes, NB stores.  Neighbours inside the slice come from LDS
-// (the slice's own data, staged behind the first burst's loads), the others from memory.  The row kernel is bound by its ~8 dependent round trips per row with 20
-// waves per CU; this one needs 1-2 with 8-12 waves.
-#ifndef BURST_NB
-#define BURST_NB 6
-#define BURST_WAVES 2
-#endif
-template <class Op> struct BurstCfg { static constexpr int NB = BURST_NB, WAVES = BURST_WAVES; };
+// (the slice's own data, staged behind the first burst's loads), the others from memory.  The row
+// kernel is bound by its ~8 dependent round trips per row with 20 waves per CU (DESIGN.md section
+// 3); this one needs 1-2 with 8 waves.
+// edges per burst / waves per SIMD asked of the compiler (measured: 6 / 2 beats 3 / 3, 2 / 4 and 1 / 4 for the
+// continuity operator; the scalar operator's 12 + 4 doubles per node / edge allow 3 per burst)
+template <class Op> struct BurstCfg { static constexpr int NB = 6, WAVES = 2; };
 template <> struct BurstCfg<ScalOp> { static constexpr int NB = 3, WAVES = 2; };
 
 template <class Op, bool SET>
