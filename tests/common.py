@@ -2,7 +2,7 @@
 the HIP library (through the C ABI)."""
 import numpy as np
 
-from fields import density, quadratic, velocity
+from nalu_amd.synth import density, quadratic, velocity
 
 
 def dense(rp, ci, v, ncols):

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from common import rel_err
-from fields import density, quadratic, quadratic_grad, velocity
+from nalu_amd.synth import density, quadratic, quadratic_grad, velocity
 
 pytestmark = pytest.mark.gpu
 

@@ -338,7 +338,7 @@ def test_full_size_properties(G, torch, oracle):
     vol, area = S.uniform_geometry()
     xyz = S.coords()
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
-    from fields import quadratic, velocity, density
+    from nalu_amd.synth import quadratic, velocity, density
     p = quadratic(xyz.T, 0)
     coords, vel = t(xyz), t(velocity(xyz.T).T)
     rho, pd, ar = t(density(xyz.T)), t(p), t(area)

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from fields import density, quadratic, velocity
+from nalu_amd.synth import density, quadratic, velocity
 
 HERE = os.path.dirname(__file__)
 
