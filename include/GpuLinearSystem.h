@@ -188,6 +188,15 @@ public:
     checkError(nalu_gpu_build_node_graph(h_, (int64_t)nodes.size(), nodes.data()), "buildNodeGraph");
   }
   // edgeNodes: 2 local node ids per edge; the edge order defines the layout of edge fields
+  // nalu_gpu_suggest_edge_order: the slot-major permutation (perm[new] = old) of an edge list, to be applied
+  // to the list and to every edge field before buildEdgeToNodeGraph (no counterpart in the reference)
+  static std::vector<int64_t> suggestEdgeOrder(const std::vector<int> &edgeNodes)
+  {
+    std::vector<int64_t> perm(edgeNodes.size() / 2);
+    if (nalu_gpu_suggest_edge_order((int64_t)perm.size(), edgeNodes.data(), perm.data()) != NALU_GPU_OK)
+      throw std::runtime_error(nalu_gpu_last_error());
+    return perm;
+  }
   void buildEdgeToNodeGraph(const std::vector<int> &edgeNodes)
   {
     beginLinearSystemConstruction();

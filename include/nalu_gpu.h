@@ -97,6 +97,15 @@ int nalu_gpu_build_node_graph(nalu_gpu_linsys *h, int64_t n_nodes, const int *no
  * touches an owned node (the locally owned ones plus the cut edges owned by neighbour
  * ranks): owned rows are computed by their owner, so loadComplete needs no matrix export. */
 int nalu_gpu_build_edge_to_node_graph(nalu_gpu_linsys *h, int64_t n_edges, const int *edge_nodes);
+/* No counterpart in the reference (STK numbers edges in creation order, and a CPU edge loop does not
+ * care).  The edge order a caller should give its edge list -- and with it every edge field --
+ * before nalu_gpu_build_edge_to_node_graph so that the row-gather kernels can compute edge ids
+ * instead of loading them and the marching kernel applies: "slot-major", i.e. all first upper
+ * edges of the nodes (in node order), then all second ones, ...; the upper edges of a node are its
+ * edges to higher local ids, in ascending order of the other node.  perm_out[new] = old index.
+ * Any order is correct; this one is the fast one on meshes whose node numbering has some
+ * regularity (on a lattice: x-, y-, z-edges).  Host-only, no handle needed. */
+int nalu_gpu_suggest_edge_order(int64_t n_edges, const int *edge_nodes, int64_t *perm_out);
 /* buildElemToNodeGraph (src/TpetraLinearSystem.C:435-440); also serves face/reduced-elem
  * graphs, which differ only in the entity rank the caller iterates. */
 int nalu_gpu_build_elem_to_node_graph(nalu_gpu_linsys *h, int64_t n_elems, int nodes_per_elem,

@@ -4,5 +4,5 @@ Krylov solve (continuity / scalar transport systems).  The product is the HIP li
 the Python-side mirror of the reference's LinearSystem interface used by tests and bench."""
 from ._lib import LIB_PATH, NaluGpuError, load  # noqa: F401
 from .box import BoxSlab, box_edges, split_elems  # noqa: F401
-from .linsys import GpuLinearSystem, LinearSolverConfig  # noqa: F401
+from .linsys import GpuLinearSystem, LinearSolverConfig, suggest_edge_order  # noqa: F401
 from . import eqsys  # noqa: F401

@@ -290,6 +290,31 @@ extern "C" int nalu_gpu_build_node_graph(nalu_gpu_linsys *h, int64_t n, const in
 {
   return add_block(h, n, 1, lids, false);
 }
+extern "C" int nalu_gpu_suggest_edge_order(int64_t n_edges, const int *edge_nodes, int64_t *perm_out)
+{
+  NG_REQUIRE(n_edges >= 0 && (n_edges == 0 || (edge_nodes && perm_out)), NALU_GPU_EINVAL, "bad edge list");
+  std::vector<int64_t> idx((size_t)n_edges);
+  for (int64_t e = 0; e < n_edges; ++e) idx[(size_t)e] = e;
+  auto lo = [&](int64_t e) { return std::min(edge_nodes[2 * e], edge_nodes[2 * e + 1]); };
+  auto hi = [&](int64_t e) { return std::max(edge_nodes[2 * e], edge_nodes[2 * e + 1]); };
+  std::sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) {
+    return lo(a) != lo(b) ? lo(a) < lo(b) : (hi(a) != hi(b) ? hi(a) < hi(b) : a < b);
+  });
+  // slot of an edge = its position among its lower node's upper edges; counting sort by slot
+  std::vector<int> slot((size_t)n_edges);
+  std::vector<int64_t> count;
+  for (int64_t q = 0; q < n_edges; ++q) {
+    const int sl = (q > 0 && lo(idx[(size_t)q]) == lo(idx[(size_t)q - 1])) ? slot[(size_t)q - 1] + 1 : 0;
+    slot[(size_t)q] = sl;
+    if ((size_t)sl >= count.size()) count.resize((size_t)sl + 1, 0);
+    ++count[(size_t)sl];
+  }
+  std::vector<int64_t> start(count.size() + 1, 0);
+  for (size_t c = 0; c < count.size(); ++c) start[c + 1] = start[c] + count[c];
+  for (int64_t q = 0; q < n_edges; ++q) perm_out[start[(size_t)slot[(size_t)q]]++] = idx[(size_t)q];
+  return NALU_GPU_OK;
+}
+
 extern "C" int nalu_gpu_build_edge_to_node_graph(nalu_gpu_linsys *h, int64_t n_edges,
                                                  const int *edge_nodes)
 {

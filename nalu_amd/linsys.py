@@ -93,6 +93,16 @@ class ScatterPlan:
             pass
 
 
+def suggest_edge_order(edge_nodes):
+    """nalu_gpu_suggest_edge_order: the slot-major permutation (perm[new] = old) of an edge list of local
+    node ids -- apply it to the edge list AND to every edge field before buildEdgeToNodeGraph."""
+    a = _np(edge_nodes, np.int32)
+    assert a.ndim == 2 and a.shape[1] == 2
+    perm = np.empty(a.shape[0], np.int64)
+    L.check(L.load().nalu_gpu_suggest_edge_order(a.shape[0], a.ctypes.data, perm.ctypes.data))
+    return perm
+
+
 class GpuLinearSystem:
     """One sierra::nalu::LinearSystem on one GPU."""
 

@@ -41,7 +41,14 @@ class BenchCase:
     order."""
 
     def __init__(self, G, oracle, dims, perturb=0.0, edge_order="slot"):
-        self.S = S = G.BoxSlab(*dims, edge_order=edge_order)
+        if edge_order == "suggested":  # (L,R)-sorted edges renumbered by nalu_gpu_suggest_edge_order
+            self.S = S = G.BoxSlab(*dims, edge_order="sorted")
+            perm = G.suggest_edge_order(S.edge_nodes)
+            assert sorted(perm.tolist()) == list(range(S.n_edges))
+            S.edge_nodes = np.ascontiguousarray(S.edge_nodes[perm])
+            S.edge_dir = S.edge_dir[perm]
+        else:
+            self.S = S = G.BoxSlab(*dims, edge_order=edge_order)
         self.dims = dims
         en = S.edge_nodes
         # oracle edge order: sorted by (L, R); to_sorted[i] = device edge index of oracle edge i
@@ -192,6 +199,30 @@ def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, pert
     assert np.array_equal(mdot.cpu().numpy(), c.mdot)
     assert np.array_equal(grad.cpu().numpy().T,
                           oracle.nodal_grad(c.en_sorted, c.area_sorted, c.vol, c.q))
+
+
+@pytest.mark.parametrize("dims,perturb", [((256, 6, 20), 0.125), ((512, 5, 9), 0.0), ((20, 20, 20), 0.125)])
+def test_suggested_edge_order_reaches_the_fast_paths(G, torch, oracle, dims, perturb):
+    """nalu_gpu_suggest_edge_order on an arbitrarily ((L,R)-sorted) numbered edge list: the general
+    "j-th upper edge of a node" rule -- no knowledge of the lattice -- gives computed edge ids and
+    marching runs like BoxSlab's own direction-major numbering, and the oracle's values bit for bit."""
+    c = BenchCase(G, oracle, dims, perturb, edge_order="suggested")
+    ref = BenchCase(G, oracle, dims, perturb, edge_order="slot")
+    d = c.dev(torch)
+    g = c.gpu_system(G)
+    li, lr = g.layout_info(), ref.gpu_system(G).layout_info()
+    assert li["assembly_variant"] == lr["assembly_variant"] and (dims != (256, 6, 20) or lr["assembly_variant"] == 4)
+    if dims[0] % 256 == 0:  # one x-line (or half of one) per slice: the same fast paths, row for row
+        for k in ("rows_computed_tags", "rows_computed_columns", "march_slices", "march_runs"):
+            assert li[k] == lr[k], (k, li, lr)
+    g.assemble_continuity_edges(d["coords"], d["dpdx"], d["vel"], d["p"], d["rho"], d["area"], c.dt)
+    g.loadComplete()
+    _equal_system(g, c.oracle_continuity())
+    g.zeroSystem()
+    g.assemble_scalar_edges(d["coords"], d["dqdx"], d["vel"], d["q"], d["rho"], d["gamma"], d["area"], d["mdot"],
+                            hybrid_factor=1.0, limiter=True)
+    g.loadComplete()
+    _equal_system(g, c.oracle_scalar(hybrid_factor=1.0, limiter=True))
 
 
 def test_sorted_and_slot_major_numbering_agree(G, torch, oracle):
