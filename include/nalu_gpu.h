@@ -384,7 +384,11 @@ enum {
   NALU_GPU_T_ZERO = 0, NALU_GPU_T_ASSEMBLE_EDGES = 1, NALU_GPU_T_SPMV = 2,
   NALU_GPU_T_SOLVE = 3, NALU_GPU_T_PRECOND = 4, NALU_GPU_T_BC = 5, NALU_GPU_T_COUNT = 6
 };
+/* enabled: 0 off, 1 every launch is timed, n > 1: the SpMV timer (one launch per Krylov iteration; an event
+ * pair costs ~4 us of stream time) times every n-th launch, the others every launch */
 int nalu_gpu_set_profiling(nalu_gpu_linsys *h, int enabled);
+/* launches seen by a timer while profiling was on (nalu_gpu_get_timer's count = the launches timed) */
+int nalu_gpu_get_timer_launches(nalu_gpu_linsys *h, int which, int64_t *launched);
 /* synchronises the stream, then returns accumulated device ms and launch count */
 int nalu_gpu_get_timer(nalu_gpu_linsys *h, int which, double *total_ms, int64_t *count);
 int nalu_gpu_reset_timers(nalu_gpu_linsys *h);

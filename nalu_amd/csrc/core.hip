@@ -60,16 +60,22 @@ static hipEvent_t get_event(nalu_gpu_linsys *h)
 void nalu_gpu::timer_begin(nalu_gpu_linsys *h, int which)
 {
   if (!h->profiling) return;
+  Timer &tm = h->timers[which];
+  // an event pair costs ~4 us of stream time: the one high-frequency timer (SpMV, once per Krylov
+  // iteration) may sample every n-th launch
+  tm.skip = which == NALU_GPU_T_SPMV && h->profiling > 1 && tm.launched % h->profiling != 0;
+  ++tm.launched;
+  if (tm.skip) return;
   EventPair p;
   p.a = get_event(h);
   p.b = get_event(h);
   (void)hipEventRecord(p.a, h->stream);
-  h->timers[which].pending.push_back(p);
+  tm.pending.push_back(p);
 }
 
 void nalu_gpu::timer_end(nalu_gpu_linsys *h, int which)
 {
-  if (!h->profiling) return;
+  if (!h->profiling || h->timers[which].skip) return;
   (void)hipEventRecord(h->timers[which].pending.back().b, h->stream);
 }
 
@@ -93,7 +99,14 @@ static void drain_timers(nalu_gpu_linsys *h)
 extern "C" int nalu_gpu_set_profiling(nalu_gpu_linsys *h, int enabled)
 {
   NG_REQUIRE(h, NALU_GPU_EINVAL, "null handle");
-  h->profiling = enabled != 0;
+  h->profiling = enabled > 0 ? enabled : 0;
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_get_timer_launches(nalu_gpu_linsys *h, int which, int64_t *launched)
+{
+  NG_REQUIRE(h && launched && which >= 0 && which < NALU_GPU_T_COUNT, NALU_GPU_EINVAL, "bad timer id");
+  *launched = h->timers[which].launched;
   return NALU_GPU_OK;
 }
 
@@ -123,6 +136,7 @@ extern "C" int nalu_gpu_reset_timers(nalu_gpu_linsys *h)
   for (int t = 0; t < NALU_GPU_T_COUNT; ++t) {
     h->timers[t].totalMs = 0.0;
     h->timers[t].count = 0;
+    h->timers[t].launched = 0;
   }
   return NALU_GPU_OK;
 }

@@ -112,7 +112,9 @@ struct EventPair {
 struct Timer {
   std::vector<EventPair> pending;
   double totalMs = 0.0;
-  long long count = 0;
+  long long count = 0;     // launches timed
+  long long launched = 0;  // launches seen while profiling (timed or not, see nalu_gpu_set_profiling)
+  bool skip = false;       // the launch between the current timer_begin / timer_end is not timed
 };
 
 constexpr int MAX_BLOCKS = 16384;  // cap of the reduction kernels' grids (partials per slot)
@@ -284,7 +286,7 @@ struct nalu_gpu_linsys {
   std::vector<nalu_gpu_scatter_plan *> plans;
 
   // timers
-  bool profiling = false;
+  int profiling = 0;  // 0 off; n >= 1: on, the SpMV timer samples every n-th launch
   nalu_gpu::Timer timers[NALU_GPU_T_COUNT];
   std::vector<hipEvent_t> eventPool;
 };

@@ -485,7 +485,14 @@ class GpuLinearSystem:
 
     # ---- timers ---------------------------------------------------------------
     def set_profiling(self, on=True):
+        """on: False / True, or n > 1: the SpMV timer times every n-th launch (an event pair costs ~4 us)"""
         L.check(self.lib.nalu_gpu_set_profiling(self.h, int(on)))
+
+    def timer_launches(self, name):
+        """launches a timer saw while profiling was on (timer()'s count: the launches timed)"""
+        n = C.c_int64()
+        L.check(self.lib.nalu_gpu_get_timer_launches(self.h, L.TIMERS[name], C.byref(n)))
+        return n.value
 
     def timer(self, name):
         ms, cnt = C.c_double(), C.c_int64()

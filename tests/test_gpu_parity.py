@@ -471,6 +471,28 @@ def test_hex8_geometry_on_device(G, torch, oracle, dims, perturb):
     assert float(vol.abs().max()) == 0.0 and float(area.abs().max()) == 0.0
 
 
+def test_profiling_timers_and_spmv_sampling(G, torch, oracle):
+    """nalu_gpu_set_profiling: HIP-event timers on the library's stream; with n > 1 the SpMV timer
+    times every n-th launch (what bench.py uses inside its timed region), the launch counter sees all."""
+    c = Case(oracle, 9, 0.0)
+    d = c.dev(torch)
+    g = c.gpu_system(G.GpuLinearSystem)
+    g.assemble_continuity_edges(d["coords"], d["dpdx"], d["vel"], d["p"], d["rho"], d["area"], c.dt)
+    g.loadComplete()
+    x = torch.rand(g.n_cols, dtype=torch.float64, device="cuda:0")
+    y = torch.empty(g.n_owned, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    for stride, timed in ((1, 7), (3, 3), (0, 0)):
+        g.set_profiling(stride)
+        g.reset_timers()
+        for _ in range(7):
+            g.spmv(x, y)
+        ms, cnt = g.timer("spmv")
+        assert cnt == timed and g.timer_launches("spmv") == (7 if stride else 0)
+        assert (ms > 0.0) == (timed > 0)
+    g.set_profiling(False)
+
+
 def test_equation_system_driver(G, torch, oracle, tmp_path):
     """EquationSystem::assemble_and_solve / SolverAlgorithmDriver::execute mirror
     (src/EquationSystem.C:263-307, src/SolverAlgorithmDriver.C:109-138): algorithms run in
