@@ -389,6 +389,13 @@ enum {
 int nalu_gpu_set_profiling(nalu_gpu_linsys *h, int enabled);
 /* launches seen by a timer while profiling was on (nalu_gpu_get_timer's count = the launches timed) */
 int nalu_gpu_get_timer_launches(nalu_gpu_linsys *h, int which, int64_t *launched);
+/* Schedule of the exact SGS sweeps (preconditioner "sgs"), valid after the first solve with it.  No counterpart
+ * in the reference (Ifpack2 sweeps rows sequentially on the host).  out[0]: 1 = dataflow sweeps (one launch per
+ * sweep), -1 = one launch per level (rows wider than the dataflow kernel takes, or NG_SGS_MODE=levels|inplace),
+ * 0 = not built yet; out[1]: 1 = lattice tiles, 0 = contiguous row chunks; out[2]: chunks; out[3]: most steps of
+ * a chunk; out[4]: widest row (entries one side of the diagonal); out[5]: LDS ring (rows); out[6], out[7]: lines
+ * and planes per tile */
+int nalu_gpu_get_sgs_schedule(nalu_gpu_linsys *h, int out[8]);
 /* synchronises the stream, then returns accumulated device ms and launch count */
 int nalu_gpu_get_timer(nalu_gpu_linsys *h, int which, double *total_ms, int64_t *count);
 int nalu_gpu_reset_timers(nalu_gpu_linsys *h);

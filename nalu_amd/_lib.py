@@ -32,7 +32,7 @@ SYMBOLS = [
     "nalu_gpu_field_axpby", "nalu_gpu_project_nodal_velocity", "nalu_gpu_compute_geometry_hex8", "nalu_gpu_set_halo_plan", "nalu_gpu_set_halo_plan_indexed",
     "nalu_gpu_set_comm", "nalu_gpu_set_callback_error", "nalu_gpu_get_halo_plan", "nalu_gpu_set_assembly_mode", "nalu_gpu_set_edge_ownership", "nalu_gpu_get_comm_buffers", "nalu_gpu_halo_exchange",
     "nalu_gpu_set_profiling", "nalu_gpu_get_timer", "nalu_gpu_get_timer_launches", "nalu_gpu_reset_timers",
-    "nalu_gpu_synchronize", "nalu_gpu_get_layout_info", "nalu_gpu_suggest_edge_order", "nalu_gpu_check_system", "nalu_gpu_set_debug", "nalu_gpu_dot_static",
+    "nalu_gpu_synchronize", "nalu_gpu_get_layout_info", "nalu_gpu_suggest_edge_order", "nalu_gpu_check_system", "nalu_gpu_set_debug", "nalu_gpu_dot_static", "nalu_gpu_get_sgs_schedule",
 ]
 
 
@@ -168,6 +168,7 @@ def load():
         "nalu_gpu_get_timer": [vp, ci, P(dbl), P(i64)],
         "nalu_gpu_get_timer_launches": [vp, ci, P(i64)],
         "nalu_gpu_reset_timers": [vp],
+        "nalu_gpu_get_sgs_schedule": [vp, P(ci)],
         "nalu_gpu_synchronize": [vp],
         "nalu_gpu_get_layout_info": [vp, P(LayoutInfo)],
         "nalu_gpu_suggest_edge_order": [i64, vp, vp],

@@ -262,6 +262,22 @@ struct nalu_gpu_linsys {
   double *dLmFwdVal = nullptr, *dLmBwdVal = nullptr, *dLmDinvF = nullptr, *dLmDinvB = nullptr;
   double *dLmR = nullptr, *dLmT = nullptr, *dLmZ = nullptr;
 
+  // dataflow SGS sweeps (precond.hip, sgs_flow.hpp): one launch per sweep, chunks of rows wait
+  // for each other through dFlowT / dFlowZ (data-as-flag)
+  int flowState = 0;  // 0 not built, 1 ready, -1 not available for this matrix (level launches instead)
+  struct FlowDir {
+    void *dChunks = nullptr;  // nalu_gpu::FlowChunk[nChunks], processing order
+    int *dRowOf = nullptr, *dCode = nullptr, *dSteps = nullptr;
+    long long *dSrc = nullptr;  // SELL position of every entry's value (-1: pad)
+    double *dVal = nullptr;
+    int nChunks = 0, wMax = 0, ring = 0, depth = 0, maxSteps = 0;
+    long long nEnt = 0;
+    size_t ldsBytes = 0;
+  } flow[2];  // forward, backward
+  double *dFlowT = nullptr, *dFlowZ = nullptr;  // nOwned each, all-ones NaN = "not computed yet"
+  bool flowTiled = false;
+  int flowTile[4] = {0, 0, 0, 0};  // Q, P, By, Bz of the lattice tiling
+
   // multicolour SGS (precond.hip): rows bucketed by greedy colour
   bool mcReady = false;
   std::vector<int> mcOff;
@@ -426,6 +442,7 @@ int finish_reduction(nalu_gpu_linsys *h, int nslots, int nblocks, const double *
 int vec_grid(int64_t n);
 void release_plan(nalu_gpu_scatter_plan *p);
 int ensure_sgs_levels(nalu_gpu_linsys *h);
+int sgs_prepare(nalu_gpu_linsys *h);  // whichever schedule NG_SGS_MODE selects
 int apply_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone);
 int sgs_compute(nalu_gpu_linsys *h);
 int ensure_mc_colors(nalu_gpu_linsys *h);

@@ -21,10 +21,12 @@
 // previous levels nearly contiguously, z is scattered back once.  Same operations in the same
 // order per row as before: bit-identical results.
 #include <algorithm>
+#include <cstring>
 #include <type_traits>
 #include <vector>
 
 #include "internal.hpp"
+#include "sgs_flow.hpp"
 
 using namespace nalu_gpu;
 
@@ -163,6 +165,252 @@ __global__ __launch_bounds__(256) void k_mc_sweep(SellView A, const int *__restr
   out[i] = FWD ? s * dinv[i] : t[i] - s * dinv[i];
 }
 
+// ---- dataflow sweeps (schedule: sgs_flow.hpp)
+// One launch per sweep, one workgroup per chunk of rows, dispatched in the schedule's order.  Wave 0
+// (the consumer) walks the chunk's steps: at most 64 independent rows each, same operations in
+// the same order per row as the sequential sweep, so the result is bit-identical to it.  Values of
+// the chunk's own earlier rows come from an LDS ring; values of other chunks are read from the
+// result vector itself, which starts as all-ones NaNs ("not computed yet", data-as-flag: an
+// 8-byte agent-scope store publishes a value, ~0.6 us from store to a polling load on MI355X,
+// scripts/flowbench.hip) -- the consumer asks for them D steps ahead and only spins when one is
+// still missing at its step.  Waves 1-3 (the loaders) stream the chunk's rows, D + 2 steps or
+// more ahead, into an LDS staging ring: matrix values, entry codes, r, 1/d, row numbers.
+// Every spin is bounded; a wave that gives up sets *err, after which no wave waits any more, the
+// grid drains and nalu_gpu_solve reports the failure.  Workgroups only wait for chunks earlier in
+// the dispatch order (flow_build checks it), which are running or finished.
+constexpr unsigned long long FLOW_SENT = ~0ull;
+constexpr int FLOW_LOADERS = 3;
+constexpr int FLOW_MAX_POLL = 1 << 20;      // ~0.6 s of polling one value
+constexpr int FLOW_MAX_LDS_SPIN = 1 << 24;  // loaders <-> consumer inside one workgroup
+
+struct FlowView {
+  const FlowChunk *chunks;
+  const int *rowOf, *code, *steps;
+  const double *val;
+  int ringMask;  // LDS ring of in-chunk values: ring - 1, ring >= largest lookback + 64
+  int wLds;      // entries per row the staging ring is laid out for
+  int maxSteps;  // most steps of any chunk (the step offsets of a chunk are copied to LDS)
+};
+
+// D: steps of look-ahead for values of other chunks; W: entries per row at most; GB: batches of
+// 64 rows a loader wave has in flight; NSR: rows of the staging ring
+template <int D, int W, int GB>
+struct FlowCfg {
+  static constexpr int GROUP = GB * 64;
+  static constexpr int NSR = (D + 2 + GB + GB - 1) / GB * GROUP;
+  static constexpr int NG = NSR / GROUP;
+  static size_t lds_bytes(int ring, int w, int maxSteps)
+  {
+    return 8u * (size_t)ring + (size_t)NSR * (20u + 12u * (size_t)w) + 4u * (size_t)(NG + 4 + maxSteps + 2);
+  }
+};
+
+__device__ __forceinline__ double flow_poll(const double *p, int *err)
+{
+  unsigned long long bits;
+  int spins = 0;
+  for (;;) {
+    bits = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bits != FLOW_SENT) break;
+    ++spins;
+    if ((spins & 15) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    if (spins >= FLOW_MAX_POLL) {
+      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return __longlong_as_double((long long)bits);
+}
+
+// FWD: flow_i = (in_i - sum_{c<i} a_ic flow_c) dinv_i              (in = r, flow = t)
+// else: flow_i = in_i - (sum_{i<c<n} a_ic flow_c) dinv_i, zout_i = flow_i   (in = t, flow = z)
+// rearm: the vector the NEXT sweep polls; the loaders reset this chunk's rows of it to "not computed"
+template <bool FWD, int D, int W, int GB>
+__global__ __launch_bounds__(64 * (1 + FLOW_LOADERS)) void k_flow_sweep(FlowView F, const int *__restrict__ done,
+                                                                        const double *in,
+                                                                        const double *__restrict__ dinv, double *flow,
+                                                                        double *zout, double *rearm, int *err)
+{
+  using Cfg = FlowCfg<D, W, GB>;
+  constexpr int NSR = Cfg::NSR, NG = Cfg::NG, GROUP = Cfg::GROUP;
+  if (done && *done) return;
+  extern __shared__ double flowLds[];
+  const int ring = F.ringMask + 1;
+  double *tring = flowLds;
+  double *sR = tring + ring;
+  double *sDV = sR + NSR;
+  double *sA = sDV + NSR;                     // [wLds][NSR]
+  int *sC = (int *)(sA + (size_t)F.wLds * NSR);  // [wLds][NSR]
+  int *sRow = sC + (size_t)F.wLds * NSR;
+  int *ready = sRow + NSR;  // [NG]: group g staged <=> ready[g % NG] == g + 1
+  int *consumed = ready + NG;
+  int *abortFlag = consumed + 1;
+  int *sSteps = abortFlag + 3;  // [nSteps + 1]: first row of every step (LDS: the consumer's only vector-memory
+                                // traffic must be its look-ahead loads and its stores, see prefetch below)
+  const FlowChunk C = F.chunks[blockIdx.x];
+  if (threadIdx.x < NG + 2) ready[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i <= C.nSteps; i += blockDim.x) sSteps[i] = F.steps[C.stepOff + i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int m = C.m, w = C.w;
+
+  if (wave > 0) {  // ---- loaders
+    const int nGroups = (m + GROUP - 1) / GROUP;
+    for (int g = wave - 1; g < nGroups; g += FLOW_LOADERS) {
+      const int need = GROUP * (g + 1) - NSR;  // rows the consumer must be done with
+      if (need > 0) {
+        int spins = 0;
+        while (__hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+          if (__hip_atomic_load(abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+          if (++spins >= FLOW_MAX_LDS_SPIN) {
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(abortFlag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      int row[GB], cd[GB][W];
+      double av[GB][W], rr[GB], dd[GB];
+#pragma unroll
+      for (int b = 0; b < GB; ++b) {
+        const int q = g * GROUP + b * 64 + lane;
+        const bool ok = q < m;
+        row[b] = ok ? F.rowOf[(size_t)C.rowOff + q] : -1;
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+          if (k < w && ok) {
+            const size_t idx = (size_t)(C.entOff + (long long)k * m + q);
+            cd[b][k] = F.code[idx];
+            av[b][k] = F.val[idx];
+          }
+      }
+#pragma unroll
+      for (int b = 0; b < GB; ++b)
+        if (row[b] >= 0) {
+          rr[b] = in[row[b]];
+          dd[b] = dinv[row[b]];
+        }
+#pragma unroll
+      for (int b = 0; b < GB; ++b)
+        if (row[b] >= 0) {
+          const int slot = (g * GROUP + b * 64 + lane) % NSR;
+          sR[slot] = rr[b];
+          sDV[slot] = dd[b];
+          sRow[slot] = row[b];
+#pragma unroll
+          for (int k = 0; k < W; ++k)
+            if (k < w) {
+              sC[k * NSR + slot] = cd[b][k];
+              sA[k * NSR + slot] = av[b][k];
+            }
+          ((unsigned long long *)rearm)[row[b]] = FLOW_SENT;
+        }
+      __hip_atomic_store(&ready[g % NG], g + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return;
+  }
+
+  // ---- consumer
+  const int nSteps = C.nSteps;
+  auto off = [&](int s) { return __builtin_amdgcn_readfirstlane(sSteps[s]); };
+  int readyUpTo = 0;
+  bool dead = false;
+  auto ensure = [&](int rowsEnd) {  // rows [0, rowsEnd) are in the staging ring
+    const int ng = (rowsEnd + GROUP - 1) / GROUP;
+    while (readyUpTo < ng) {
+      int spins = 0;
+      while (__hip_atomic_load(&ready[readyUpTo % NG], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < readyUpTo + 1) {
+        if (__hip_atomic_load(abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) || ++spins >= FLOW_MAX_LDS_SPIN) {
+          __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(abortFlag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          dead = true;
+          return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      ++readyUpTo;
+    }
+  };
+  const double sentD = __longlong_as_double((long long)FLOW_SENT);
+  // values of other chunks for step s, asked for D steps ahead: the first two external entries of
+  // every row (always two loads, so that the compiler can count what is in flight)
+  // Steps past the end are empty: the two loads are issued on EVERY path, or the compiler, which
+  // counts what is in flight per path, would wait for all of them at every step.
+  auto prefetch = [&](int s, double &e0, double &e1) {
+    const int p0 = off(min(s, nSteps)), p1 = off(min(s + 1, nSteps));
+    ensure(p1);
+    int g0 = -1, g1 = -1;
+    const int q = p0 + lane;
+    if (!dead && q < p1) {
+      const int slot = q % NSR;
+      for (int k = 0; k < w; ++k) {
+        const int c = sC[k * NSR + slot];
+        if (c == FLOW_PAD) break;
+        if (c < 0) {
+          if (g0 < 0) g0 = ~c;
+          else { g1 = ~c; break; }
+        }
+      }
+    }
+    // (rows without such an entry read flow[0] and never look at the result: no select here, the
+    // loaded registers must not be touched before their step)
+    e0 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + max(g0, 0)),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    e1 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + max(g1, 0)),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  };
+  auto consume = [&](int s, double e0, double e1) {
+    const int s0 = off(s), s1 = off(s + 1);
+    ensure(s1);
+    if (dead) return;
+    const int q = s0 + lane;
+    if (q < s1) {
+      const int slot = q % NSR;
+      const double own = sR[slot];
+      double acc = FWD ? own : 0.0;
+      int e = 0;
+      for (int k = 0; k < w; ++k) {
+        const int c = sC[k * NSR + slot];
+        if (c == FLOW_PAD) break;
+        double v;
+        if (c > 0) v = tring[(q - c) & F.ringMask];
+        else {
+          v = e == 0 ? e0 : e == 1 ? e1 : sentD;
+          ++e;
+          if ((unsigned long long)__double_as_longlong(v) == FLOW_SENT) v = flow_poll(flow + ~c, err);
+        }
+        const double a = sA[k * NSR + slot];
+        acc = FWD ? acc - a * v : acc + a * v;
+      }
+      const double out = FWD ? acc * sDV[slot] : own - acc * sDV[slot];
+      const int row = sRow[slot];
+      tring[q & F.ringMask] = out;
+      __hip_atomic_store((unsigned long long *)(flow + row), (unsigned long long)__double_as_longlong(out),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!FWD) zout[row] = out;
+    }
+    __hip_atomic_store(consumed, s1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  double ex0[D], ex1[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    prefetch(j, ex0[j], ex1[j]);
+  }
+  for (int sb = 0; sb < nSteps && !dead; sb += D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const int s = sb + j;
+      if (s < nSteps) consume(s, ex0[j], ex1[j]);
+      prefetch(s + D, ex0[j], ex1[j]);
+    }
+  }
+}
+
 // rows sorted by level (ascending row inside a level) + level offsets
 void bucket_by_level(const std::vector<int> &level, int nLevels, std::vector<int> &rows,
                      std::vector<int> &off)
@@ -280,13 +528,159 @@ int nalu_gpu::ensure_sgs_levels(nalu_gpu_linsys *h)
   return NALU_GPU_OK;
 }
 
+// ---- which schedule runs the exact SGS sweeps
+//   NG_SGS_MODE=flow (default): the dataflow sweeps, one launch each way (level launches if the
+//   matrix has rows with more than 16 lower or upper entries); levels: one launch per level on the
+//   level-major copy (round 2's first version); inplace (or NG_SGS_INPLACE=1): one launch per level
+//   on the SELL matrix itself (round 1).  All three give bit-identical results.
+namespace {
+enum { SGS_FLOW = 0, SGS_LEVELS = 1, SGS_INPLACE = 2 };
+int sgs_mode()
+{
+  const char *m = getenv("NG_SGS_MODE");
+  if (m && !strcmp(m, "levels")) return SGS_LEVELS;
+  if (m && !strcmp(m, "inplace")) return SGS_INPLACE;
+  if (getenv("NG_SGS_INPLACE") && atoi(getenv("NG_SGS_INPLACE")) != 0) return SGS_INPLACE;
+  return SGS_FLOW;
+}
+using FlowA = FlowCfg<8, 4, 4>;   // rows of at most 4 entries a side (7-point graphs): deep look-ahead
+using FlowB = FlowCfg<2, 16, 1>;  // up to 16 (27-point graphs)
+constexpr size_t FLOW_MAX_LDS = 96 * 1024;
+
+template <class T>
+int flow_upload(const std::vector<T> &v, T **dst)
+{
+  NG_HIP(hipMalloc(dst, sizeof(T) * std::max<size_t>(v.size(), 1)));
+  NG_HIP(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+  return NALU_GPU_OK;
+}
+
+template <bool FWD>
+int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *flow, double *zout, double *rearm)
+{
+  const nalu_gpu_linsys::FlowDir &fd = h->flow[FWD ? 0 : 1];
+  FlowView F;
+  F.chunks = (const FlowChunk *)fd.dChunks;
+  F.rowOf = fd.dRowOf;
+  F.code = fd.dCode;
+  F.steps = fd.dSteps;
+  F.val = fd.dVal;
+  F.ringMask = fd.ring - 1;
+  F.wLds = std::max(fd.wMax, 1);
+  F.maxSteps = fd.maxSteps;
+  int *err = (int *)(h->dReduce + REDUCE_CAP) + 2;
+  const dim3 block(64 * (1 + FLOW_LOADERS));
+  if (fd.depth == 8)
+    k_flow_sweep<FWD, 8, 4, 4><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
+  else
+    k_flow_sweep<FWD, 2, 16, 1><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+// builds the dataflow schedule of both sweeps (once per graph); flowState = -1 if it cannot be used
+int ensure_sgs_flow(nalu_gpu_linsys *h)
+{
+  if (h->flowState != 0) return NALU_GPU_OK;
+  const int n = h->nOwned;
+  h->flowState = -1;
+  if (n == 0) return NALU_GPU_OK;
+  int chunkRows = getenv("NG_SGS_CHUNK") ? atoi(getenv("NG_SGS_CHUNK")) : 1024;
+  chunkRows = std::min(std::max(chunkRows, 64), 2048);
+  int By = 8, Bz = 8;
+  if (const char *t = getenv("NG_SGS_TILE")) {
+    if (sscanf(t, "%d,%d", &By, &Bz) != 2) By = Bz = 0;  // anything else: contiguous chunks only
+  }
+  std::vector<int> chunkOf;
+  FlowTiling T = flow_chunking(n, h->rowPtr.data(), h->colIdx.data(), chunkRows, By, Bz, chunkOf);
+  FlowSchedule S[2];
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    bool ok = true;
+    for (int dir = 0; dir < 2 && ok; ++dir)
+      ok = flow_build(n, h->rowPtr.data(), h->colIdx.data(), chunkOf, T.nChunks, dir == 0, S[dir]).empty();
+    for (int dir = 0; dir < 2 && ok; ++dir) ok = S[dir].maxLookback + FLOW_STEP <= 4096;
+    if (ok) break;
+    if (!T.tiled) return NALU_GPU_OK;  // contiguous chunks are always a valid order: only the ring can fail
+    T = flow_chunking(n, h->rowPtr.data(), h->colIdx.data(), chunkRows, 0, 0, chunkOf);
+  }
+  for (int dir = 0; dir < 2; ++dir) {
+    nalu_gpu_linsys::FlowDir &fd = h->flow[dir];
+    const FlowSchedule &s = S[dir];
+    int ring = 64;
+    while (ring < s.maxLookback + FLOW_STEP) ring *= 2;
+    if (ring > 4096 || s.wMax > 16) return NALU_GPU_OK;
+    const int wl = std::max(s.wMax, 1);
+    fd.depth = s.wMax <= 4 ? 8 : 2;
+    fd.ldsBytes = fd.depth == 8 ? FlowA::lds_bytes(ring, wl, s.maxSteps) : FlowB::lds_bytes(ring, wl, s.maxSteps);
+    if (fd.ldsBytes > FLOW_MAX_LDS) return NALU_GPU_OK;
+    fd.ring = ring;
+    fd.wMax = s.wMax;
+    fd.maxSteps = s.maxSteps;
+    fd.nChunks = (int)s.chunks.size();
+    fd.nEnt = (long long)s.code.size();
+  }
+  for (int dir = 0; dir < 2; ++dir) {
+    nalu_gpu_linsys::FlowDir &fd = h->flow[dir];
+    FlowSchedule &s = S[dir];
+    // CSR entry -> position of its value in the SELL matrix
+    for (const FlowChunk &C : s.chunks)
+      for (int q = 0; q < C.m; ++q) {
+        const int i = s.rowOf[(size_t)C.rowOff + q];
+        const long long so = h->hSliceOff[i / SELL_C] + i % SELL_C;
+        for (int k = 0; k < C.w; ++k) {
+          long long &e = s.src[(size_t)(C.entOff + (long long)k * C.m + q)];
+          if (e >= 0) e = so + (e - h->rowPtr[i]) * SELL_C;
+        }
+      }
+    FlowChunk *dc = nullptr;
+    NG_TRY(flow_upload(s.chunks, &dc));
+    fd.dChunks = dc;
+    NG_TRY(flow_upload(s.rowOf, &fd.dRowOf));
+    NG_TRY(flow_upload(s.code, &fd.dCode));
+    NG_TRY(flow_upload(s.steps, &fd.dSteps));
+    NG_TRY(flow_upload(s.src, &fd.dSrc));
+    NG_HIP(hipMalloc(&fd.dVal, sizeof(double) * (size_t)fd.nEnt));
+    s = FlowSchedule();
+  }
+  NG_HIP(hipMalloc(&h->dFlowT, sizeof(double) * (size_t)n));
+  NG_HIP(hipMalloc(&h->dFlowZ, sizeof(double) * (size_t)n));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 2, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 2, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  h->flowTiled = T.tiled;
+  h->flowTile[0] = T.Q; h->flowTile[1] = T.P; h->flowTile[2] = T.By; h->flowTile[3] = T.Bz;
+  h->flowState = 1;
+  return NALU_GPU_OK;
+}
+
+bool flow_active(const nalu_gpu_linsys *h) { return sgs_mode() == SGS_FLOW && h->flowState == 1; }
+}  // namespace
+
+int nalu_gpu::sgs_prepare(nalu_gpu_linsys *h)
+{
+  if (sgs_mode() == SGS_FLOW) {
+    NG_TRY(ensure_sgs_flow(h));
+    if (h->flowState == 1) return NALU_GPU_OK;
+  }
+  return ensure_sgs_levels(h);
+}
+
 // Ifpack2 compute() for SGS: refresh the level-major copies of the matrix values and of dinv
 // (the matrix changes between solves, the level structure does not).  dDinv must be ready.
 int nalu_gpu::sgs_compute(nalu_gpu_linsys *h)
 {
-  NG_TRY(ensure_sgs_levels(h));
+  NG_TRY(sgs_prepare(h));
   const int n = h->nOwned;
   if (n == 0) return NALU_GPU_OK;
+  if (flow_active(h)) {  // the values in schedule order; both result vectors "not computed yet"
+    for (auto &fd : h->flow)
+      k_lm_gather_vals<<<(unsigned)((fd.nEnt + 255) / 256), 256, 0, h->stream>>>(fd.nEnt, fd.dSrc, h->dVals, fd.dVal);
+    NG_HIP(hipGetLastError());
+    NG_HIP(hipMemsetAsync(h->dFlowT, 0xFF, sizeof(double) * (size_t)n, h->stream));
+    NG_HIP(hipMemsetAsync(h->dFlowZ, 0xFF, sizeof(double) * (size_t)n, h->stream));
+    return NALU_GPU_OK;
+  }
   k_lm_gather_vals<<<(unsigned)((h->lmFwdN + 255) / 256), 256, 0, h->stream>>>(h->lmFwdN, h->dLmFwdSrc, h->dVals,
                                                                                 h->dLmFwdVal);
   k_lm_gather_vals<<<(unsigned)((h->lmBwdN + 255) / 256), 256, 0, h->stream>>>(h->lmBwdN, h->dLmBwdSrc, h->dVals,
@@ -302,9 +696,18 @@ int nalu_gpu::sgs_compute(nalu_gpu_linsys *h)
 // sweeps on the SELL matrix itself, 5x slower at 256^3), kept as the cross-check of the tests.
 int nalu_gpu::apply_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone)
 {
-  NG_TRY(ensure_sgs_levels(h));
+  NG_TRY(sgs_prepare(h));
+  if (flow_active(h)) {
+    if (h->nOwned == 0) return NALU_GPU_OK;
+    const int *done = useDone ? &h->dScal->done : nullptr;
+    // t = (D + L)^-1 r into dFlowT (polled), then z = t - D^-1 U z into dFlowZ (polled) and z; each
+    // sweep resets the vector the next one polls (sgs_compute did it for the first)
+    NG_TRY(flow_launch<true>(h, done, r, h->dFlowT, nullptr, h->dFlowZ));
+    NG_TRY(flow_launch<false>(h, done, h->dFlowT, h->dFlowZ, z, h->dFlowT));
+    return NALU_GPU_OK;
+  }
   const int nf = (int)h->sgsFwdOff.size() - 1, nb = (int)h->sgsBwdOff.size() - 1;
-  static const bool inplace = getenv("NG_SGS_INPLACE") && atoi(getenv("NG_SGS_INPLACE")) != 0;
+  const bool inplace = sgs_mode() == SGS_INPLACE;
   if (inplace) {
     const SellView A = sell_view(h);
     const SolverScalars *sc = useDone ? h->dScal : nullptr;
@@ -396,5 +799,20 @@ int nalu_gpu::apply_mc_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool 
                                                                   nullptr, h->dT, z);
   }
   NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_get_sgs_schedule(nalu_gpu_linsys *h, int out[8])
+{
+  NG_REQUIRE(h && out, NALU_GPU_EINVAL, "null argument");
+  const bool flow = h->flowState == 1 && sgs_mode() == SGS_FLOW;
+  out[0] = flow ? 1 : (h->flowState != 0 || h->sgsReady) ? -1 : 0;
+  out[1] = flow && h->flowTiled;
+  out[2] = flow ? h->flow[0].nChunks : 0;
+  out[3] = flow ? std::max(h->flow[0].maxSteps, h->flow[1].maxSteps) : 0;
+  out[4] = flow ? std::max(h->flow[0].wMax, h->flow[1].wMax) : 0;
+  out[5] = flow ? std::max(h->flow[0].ring, h->flow[1].ring) : 0;
+  out[6] = flow ? h->flowTile[2] : 0;
+  out[7] = flow ? h->flowTile[3] : 0;
   return NALU_GPU_OK;
 }

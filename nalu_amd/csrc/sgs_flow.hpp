@@ -1,0 +1,217 @@
+// sgs_flow.hpp -- schedule of the dataflow Gauss-Seidel sweeps (precond.hip), host side.
+//
+// The exact sequential sweep of Ifpack2's SGS (src/LinearSolverConfig.C:71-75) is a chain of
+// 3n - 2 dependent levels on an n^3 lattice.  One launch per level costs a kernel boundary per
+// level; here ONE launch per sweep runs every chunk of rows in its own workgroup and lets the
+// chunks wait for each other through memory (data-as-flag, see precond.hip):
+//   * a chunk is a set of rows; the chunks form a list in which every row only depends on rows
+//     of its own chunk or of EARLIER chunks (checked here, so workgroups dispatched in list
+//     order can never wait for one that is not running);
+//   * inside a chunk the rows are sorted by their local level (counting only the dependencies
+//     inside the chunk) and cut into steps of at most 64 independent rows: one wavefront walks
+//     the steps, in-chunk values travel through an LDS ring, values of other chunks are polled;
+//   * per compact row p: rowOf[p] (the matrix row) and w entries in ascending column order (the
+//     order of the sequential sweep's sum): code > 0 = the value is p - code rows back in this
+//     chunk, code < 0 = ~code is the row of another chunk, FLOW_PAD = no entry.
+// Plain C++ (no HIP): scripts/flowcheck.cpp replays the schedule on the CPU against the
+// sequential sweep.
+#pragma once
+#include <algorithm>
+#include <climits>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace nalu_gpu {
+
+constexpr int FLOW_PAD = INT_MIN;
+constexpr int FLOW_STEP = 64;  // rows per step: one wavefront
+
+struct FlowChunk {   // 32 bytes, read by the device
+  long long entOff;  // entry k of compact row q of the chunk: entOff + k * m + q
+  int rowOff;        // first compact row of the chunk (index into rowOf)
+  int m;             // rows
+  int w;             // entries per row (padded with FLOW_PAD)
+  int stepOff;       // index of the chunk's step offsets in steps[]: nSteps + 1 chunk-relative row offsets
+  int nSteps;
+  int pad;
+};
+
+struct FlowSchedule {
+  std::vector<FlowChunk> chunks;  // in processing (= dispatch) order
+  std::vector<int> rowOf;         // n: matrix row of every compact row
+  std::vector<int> code;          // entries
+  std::vector<long long> src;     // entries: CSR entry index the value comes from (-1: pad)
+  std::vector<int> steps;
+  int wMax = 0;                   // widest chunk
+  int maxLookback = 0;            // largest in-chunk distance p - p(dep)
+  int maxSteps = 0;
+  long long nExternal = 0;
+};
+
+// chunkOf[i] = position of row i's chunk in the FORWARD processing order (0 .. nChunks-1); the
+// backward sweep processes the same chunks in reverse.  Returns an empty string, or the reason
+// this chunking cannot be used (a dependency on a later chunk).
+inline std::string flow_build(int n, const int64_t *rowPtr, const int *colIdx, const std::vector<int> &chunkOf,
+                              int nChunks, bool fwd, FlowSchedule &S)
+{
+  S = FlowSchedule();
+  // rows of every chunk, ascending
+  std::vector<int> cnt((size_t)nChunks + 1, 0);
+  for (int i = 0; i < n; ++i) ++cnt[(size_t)chunkOf[i] + 1];
+  for (int c = 0; c < nChunks; ++c) cnt[c + 1] += cnt[c];
+  std::vector<int> rows((size_t)n);
+  {
+    std::vector<int> cur(cnt.begin(), cnt.end() - 1);
+    for (int i = 0; i < n; ++i) rows[cur[chunkOf[i]]++] = i;
+  }
+  auto is_dep = [&](int i, int c) { return fwd ? c < i : (c > i && c < n); };
+  std::vector<int> lvl((size_t)n, 0), pos((size_t)n, 0);
+  S.rowOf.resize((size_t)n);
+  S.chunks.reserve((size_t)nChunks);
+  long long entTotal = 0;
+  int rowOff = 0;
+  std::vector<int> lcount, sorted;
+  for (int oc = 0; oc < nChunks; ++oc) {
+    const int c = fwd ? oc : nChunks - 1 - oc;
+    const int b = cnt[c], e = cnt[c + 1], m = e - b;
+    if (m == 0) continue;
+    // local levels: only the dependencies inside the chunk count
+    int nl = 0, w = 0;
+    for (int t = 0; t < m; ++t) {
+      const int i = fwd ? rows[b + t] : rows[e - 1 - t];
+      int l = 0, deps = 0;
+      for (int64_t k = rowPtr[i]; k < rowPtr[i + 1]; ++k) {
+        const int col = colIdx[k];
+        if (!is_dep(i, col)) continue;
+        ++deps;
+        if (chunkOf[col] == c) l = std::max(l, lvl[col] + 1);
+        else if (fwd ? chunkOf[col] > c : chunkOf[col] < c)
+          return "row " + std::to_string(i) + " depends on row " + std::to_string(col) + " of a later chunk";
+      }
+      lvl[i] = l;
+      nl = std::max(nl, l + 1);
+      w = std::max(w, deps);
+    }
+    // counting sort by level, ascending row inside a level
+    lcount.assign((size_t)nl + 1, 0);
+    for (int t = b; t < e; ++t) ++lcount[(size_t)lvl[rows[t]] + 1];
+    for (int l = 0; l < nl; ++l) lcount[l + 1] += lcount[l];
+    FlowChunk C{};
+    C.entOff = entTotal;
+    C.rowOff = rowOff;
+    C.m = m;
+    C.w = w;
+    C.stepOff = (int)S.steps.size();
+    for (int l = 0; l < nl; ++l)
+      for (int q = lcount[l]; q < lcount[l + 1]; q += FLOW_STEP) S.steps.push_back(q);
+    S.steps.push_back(m);
+    C.nSteps = (int)S.steps.size() - 1 - C.stepOff;
+    S.maxSteps = std::max(S.maxSteps, C.nSteps);
+    sorted.assign(lcount.begin(), lcount.end() - 1);
+    for (int t = b; t < e; ++t) {
+      const int i = rows[t];
+      const int q = sorted[lvl[i]]++;
+      pos[i] = q;
+      S.rowOf[(size_t)rowOff + q] = i;
+    }
+    S.code.resize((size_t)(entTotal + (long long)w * m), FLOW_PAD);
+    S.src.resize((size_t)(entTotal + (long long)w * m), -1);
+    for (int t = b; t < e; ++t) {
+      const int i = rows[t], q = pos[i];
+      int kk = 0;
+      for (int64_t k = rowPtr[i]; k < rowPtr[i + 1]; ++k) {
+        const int col = colIdx[k];
+        if (!is_dep(i, col)) continue;
+        const size_t idx = (size_t)(entTotal + (long long)kk * m + q);
+        S.src[idx] = k;
+        if (chunkOf[col] == c) {
+          const int back = q - pos[col];  // > 0: a lower level sorts first
+          S.code[idx] = back;
+          S.maxLookback = std::max(S.maxLookback, back);
+        } else {
+          S.code[idx] = ~col;
+          ++S.nExternal;
+        }
+        ++kk;
+      }
+    }
+    S.wMax = std::max(S.wMax, w);
+    entTotal += (long long)w * m;
+    rowOff += m;
+    S.chunks.push_back(C);
+  }
+  if (S.code.empty()) { S.code.push_back(FLOW_PAD); S.src.push_back(-1); }
+  return std::string();
+}
+
+// Chunking.  Contiguous runs of `chunkRows` rows are always valid (a row only depends on lower
+// rows in the forward sweep, on higher rows in the backward one).  On a lattice-numbered mesh
+// (row = x + Q y + P z: the three dominant lower offsets are 1 < Q < P with Q | P) tiles of
+// By lines x Bz planes put most y and z dependencies inside the chunk and leave
+// ny/By + nz/Bz chunk-to-chunk hops on the critical path instead of ny + nz.
+struct FlowTiling {
+  bool tiled = false;
+  int Q = 0, P = 0, By = 0, Bz = 0;
+  int nChunks = 0;
+};
+
+inline FlowTiling flow_chunking(int n, const int64_t *rowPtr, const int *colIdx, int chunkRows, int By, int Bz,
+                                std::vector<int> &chunkOf)
+{
+  FlowTiling T;
+  chunkOf.resize((size_t)n);
+  // dominant lower offsets
+  int Q = 0, P = 0;
+  if (n > 0 && By > 0 && Bz > 0) {
+    // the most frequent offset i - c over first (farthest) lower entries = P, over rows' second = Q
+    std::vector<std::pair<int, int>> h1, h2;  // small maps: offset -> count
+    auto bump = [](std::vector<std::pair<int, int>> &h, int off) {
+      for (auto &p : h)
+        if (p.first == off) { ++p.second; return; }
+      if (h.size() < 64) h.push_back({off, 1});
+    };
+    long long rows3 = 0;
+    for (int i = 0; i < n; ++i) {
+      int lower[3], nlow = 0;
+      for (int64_t k = rowPtr[i]; k < rowPtr[i + 1] && colIdx[k] < i; ++k) {
+        if (nlow < 3) lower[nlow] = colIdx[k];
+        ++nlow;
+      }
+      if (nlow != 3 || lower[2] != i - 1) continue;
+      ++rows3;
+      bump(h1, i - lower[0]);
+      bump(h2, i - lower[1]);
+    }
+    auto top = [](const std::vector<std::pair<int, int>> &h, long long &count) {
+      int best = 0;
+      count = 0;
+      for (auto &p : h)
+        if (p.second > count) { count = p.second; best = p.first; }
+      return best;
+    };
+    long long c1 = 0, c2 = 0;
+    const int p1 = top(h1, c1), q1 = top(h2, c2);
+    if (rows3 * 2 >= n && c1 * 10 >= rows3 * 9 && c2 * 10 >= rows3 * 9 && q1 > 1 && p1 > q1 && p1 % q1 == 0) {
+      P = p1;
+      Q = q1;
+    }
+  }
+  if (P > 0) {
+    const long long blockRows = (long long)By * Q;
+    const int nYb = (int)((P + blockRows - 1) / blockRows);
+    for (int i = 0; i < n; ++i) {
+      const int zb = i / P, within = i % P;
+      chunkOf[i] = (zb / Bz) * nYb + (int)(within / blockRows);
+    }
+    T.tiled = true;
+    T.Q = Q; T.P = P; T.By = By; T.Bz = Bz;
+    T.nChunks = ((n - 1) / P / Bz + 1) * nYb;
+  } else {
+    for (int i = 0; i < n; ++i) chunkOf[i] = i / chunkRows;
+    T.nChunks = n ? (n - 1) / chunkRows + 1 : 0;
+  }
+  return T;
+}
+
+}  // namespace nalu_gpu

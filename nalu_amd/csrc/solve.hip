@@ -1743,7 +1743,7 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
     k_extract_dinv<<<(h->nOwned + 255) / 256, 256, 0, h->stream>>>(h->nOwned, h->dDiagPos, h->dVals,
                                                                    cfg->precond != NALU_GPU_PRECOND_NONE,
                                                                    h->dDinv, dBad);
-  if (cfg->precond == NALU_GPU_PRECOND_SGS) NG_TRY(ensure_sgs_levels(h));
+  if (cfg->precond == NALU_GPU_PRECOND_SGS) NG_TRY(sgs_prepare(h));
   if (cfg->precond == NALU_GPU_PRECOND_MT_SGS) NG_TRY(ensure_mc_colors(h));
   NG_HIP(hipGetLastError());
   NG_TRY(halo_exchange(h, h->dDinv));
@@ -1788,8 +1788,13 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
   NG_TRY(finish_reduction(h, 2, vb));
   double *pin = (double *)((char *)h->hPinned + 1024);
   NG_HIP(hipMemcpyAsync(pin, h->dReduce, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  int *flowErr = (int *)((char *)h->hPinned + 3072) + 2;
+  NG_HIP(hipMemcpyAsync(flowErr, dBad + 2, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   SolverScalars sc;
   NG_TRY(read_scalars(h, &sc));
+  NG_REQUIRE(*flowErr == 0, NALU_GPU_ESTATE,
+             "sgs: a dataflow sweep gave up waiting for rows of another chunk (workgroups not dispatched in order, "
+             "or an all-ones NaN in the residual); NG_SGS_MODE=levels selects the sweeps with one launch per level");
   const auto t2 = std::chrono::steady_clock::now();
   info->iters = sc.iter;
   info->final_resid = std::sqrt(pin[0]);

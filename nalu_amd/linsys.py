@@ -488,6 +488,14 @@ class GpuLinearSystem:
         """on: False / True, or n > 1: the SpMV timer times every n-th launch (an event pair costs ~4 us)"""
         L.check(self.lib.nalu_gpu_set_profiling(self.h, int(on)))
 
+    def sgs_schedule(self):
+        """how the exact SGS sweeps run (nalu_gpu_get_sgs_schedule): dict with mode 'flow' / 'levels' / None"""
+        out = (C.c_int * 8)()
+        L.check(self.lib.nalu_gpu_get_sgs_schedule(self.h, out))
+        mode = {1: "flow", -1: "levels", 0: None}[out[0]]
+        return dict(mode=mode, tiled=bool(out[1]), chunks=out[2], max_steps=out[3], widest_row=out[4],
+                    ring=out[5], tile=(out[6], out[7]))
+
     def timer_launches(self, name):
         """launches a timer saw while profiling was on (timer()'s count: the launches timed)"""
         n = C.c_int64()
