@@ -21,7 +21,9 @@
 // previous levels nearly contiguously, z is scattered back once.  Same operations in the same
 // order per row as before: bit-identical results.
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
+#include <string>
 #include <type_traits>
 #include <vector>
 
@@ -173,13 +175,17 @@ __global__ __launch_bounds__(256) void k_mc_sweep(SellView A, const int *__restr
 // result vector itself, which starts as all-ones NaNs ("not computed yet", data-as-flag: an
 // 8-byte agent-scope store publishes a value, ~0.6 us from store to a polling load on MI355X,
 // scripts/flowbench.hip) -- the consumer asks for them D steps ahead and only spins when one is
-// still missing at its step.  Waves 1-3 (the loaders) stream the chunk's rows, D + 2 steps or
-// more ahead, into an LDS staging ring: matrix values, entry codes, r, 1/d, row numbers.
+// still missing at its step.  Wave 1 (the publisher) stores the computed values from the LDS ring
+// to memory; waves 2-3 (the loaders) stream the chunk's rows, D + 2 steps or more ahead, into an
+// LDS staging ring: matrix values, entry codes, r, 1/d, row numbers.
 // Every spin is bounded; a wave that gives up sets *err, after which no wave waits any more, the
 // grid drains and nalu_gpu_solve reports the failure.  Workgroups only wait for chunks earlier in
 // the dispatch order (flow_build checks it), which are running or finished.
 constexpr unsigned long long FLOW_SENT = ~0ull;
-constexpr int FLOW_LOADERS = 3;
+constexpr int FLOW_REARM = 0x40000000;  // rowOf bit 30 (set in ensure_sgs_flow): visible in the OTHER sweep's schedule
+constexpr int FLOW_ROW_MASK = 0x3fffffff;
+constexpr int FLOW_LOADERS = 2;       // waves 2 and 3 (wave 0: consumer, wave 1: publisher)
+constexpr int FLOW_PUB_WINDOW = 512;  // rows the publisher may lag behind the consumer
 constexpr int FLOW_MAX_POLL = 1 << 20;      // ~0.6 s of polling one value
 constexpr int FLOW_MAX_LDS_SPIN = 1 << 24;  // loaders <-> consumer inside one workgroup
 
@@ -190,6 +196,7 @@ struct FlowView {
   int ringMask;  // LDS ring of in-chunk values: ring - 1, ring >= largest lookback + 64
   int wLds;      // entries per row the staging ring is laid out for
   int maxSteps;  // most steps of any chunk (the step offsets of a chunk are copied to LDS)
+  long long *trace;  // development aid (NG_SGS_TRACE): per chunk, clock at start / after the first step / at the end
 };
 
 // D: steps of look-ahead for values of other chunks; W: entries per row at most; GB: batches of
@@ -201,7 +208,7 @@ struct FlowCfg {
   static constexpr int NG = NSR / GROUP;
   static size_t lds_bytes(int ring, int w, int maxSteps)
   {
-    return 8u * (size_t)ring + (size_t)NSR * (20u + 12u * (size_t)w) + 4u * (size_t)(NG + 4 + maxSteps + 2);
+    return 8u * (size_t)ring + (size_t)NSR * (28u + 12u * (size_t)w) + 4u * (size_t)(NG + 4 + maxSteps + 2);
   }
 };
 
@@ -218,7 +225,10 @@ __device__ __forceinline__ double flow_poll(const double *p, int *err)
       __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
-    __builtin_amdgcn_s_sleep(1);
+    // back off: a chunk that starts long before its turn must not flood the memory fabric with polls
+    if (spins < 4) __builtin_amdgcn_s_sleep(1);
+    else if (spins < 16) __builtin_amdgcn_s_sleep(8);
+    else __builtin_amdgcn_s_sleep(32);
   }
   return __longlong_as_double((long long)bits);
 }
@@ -227,7 +237,7 @@ __device__ __forceinline__ double flow_poll(const double *p, int *err)
 // else: flow_i = in_i - (sum_{i<c<n} a_ic flow_c) dinv_i, zout_i = flow_i   (in = t, flow = z)
 // rearm: the vector the NEXT sweep polls; the loaders reset this chunk's rows of it to "not computed"
 template <bool FWD, int D, int W, int GB>
-__global__ __launch_bounds__(64 * (1 + FLOW_LOADERS)) void k_flow_sweep(FlowView F, const int *__restrict__ done,
+__global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView F, const int *__restrict__ done,
                                                                         const double *in,
                                                                         const double *__restrict__ dinv, double *flow,
                                                                         double *zout, double *rearm, int *err)
@@ -243,13 +253,16 @@ __global__ __launch_bounds__(64 * (1 + FLOW_LOADERS)) void k_flow_sweep(FlowView
   double *sA = sDV + NSR;                     // [wLds][NSR]
   int *sC = (int *)(sA + (size_t)F.wLds * NSR);  // [wLds][NSR]
   int *sRow = sC + (size_t)F.wLds * NSR;
-  int *ready = sRow + NSR;  // [NG]: group g staged <=> ready[g % NG] == g + 1
-  int *consumed = ready + NG;
+  int *sG0 = sRow + NSR;  // rows of the first two entries that belong to other chunks (0: none)
+  int *sG1 = sG0 + NSR;
+  int *ready = sG1 + NSR;  // [NG]: group g staged <=> ready[g % NG] == g + 1
+  int *consumed = ready + NG;      // rows the consumer has computed (their values are in tring)
   int *abortFlag = consumed + 1;
+  int *published = abortFlag + 1;  // rows the publisher has stored: their staging rows and ring slots are free
   int *sSteps = abortFlag + 3;  // [nSteps + 1]: first row of every step (LDS: the consumer's only vector-memory
                                 // traffic must be its look-ahead loads and its stores, see prefetch below)
   const FlowChunk C = F.chunks[blockIdx.x];
-  if (threadIdx.x < NG + 2) ready[threadIdx.x] = 0;
+  if (threadIdx.x < NG + 4) ready[threadIdx.x] = 0;
   for (int i = threadIdx.x; i <= C.nSteps; i += blockDim.x) sSteps[i] = F.steps[C.stepOff + i];
   __syncthreads();
 
@@ -257,13 +270,52 @@ __global__ __launch_bounds__(64 * (1 + FLOW_LOADERS)) void k_flow_sweep(FlowView
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int m = C.m, w = C.w;
 
-  if (wave > 0) {  // ---- loaders
+  // rows without an entry of another chunk ask for this row's value instead (any valid address; one
+  // per chunk, or every workgroup would hit the same memory channel twice per step)
+  const int dummyRow = F.rowOf[C.rowOff] & FLOW_ROW_MASK;
+
+  if (wave == 1) {  // ---- publisher: the computed values out of the LDS ring to memory
+    // (the consumer itself issues no store: vector-memory operations retire in order, and a wait for
+    // its look-ahead loads would also wait for every older store to be acknowledged by memory)
+    int pub = 0, spins = 0;
+    while (pub < m) {
+      const int have = __hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (have <= pub) {
+        if (__hip_atomic_load(abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+        if (++spins >= FLOW_MAX_LDS_SPIN) {
+          __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(abortFlag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          return;
+        }
+        continue;
+      }
+      spins = 0;
+      for (int q0 = pub; q0 < have; q0 += 64) {
+        const int q = q0 + lane;
+        if (q < have) {
+          const double v = tring[q & F.ringMask];
+          const int raw = sRow[q % NSR], row = raw & FLOW_ROW_MASK;
+          // rows that other chunks read are published at once; the rest is only needed after the sweep
+          if (raw < 0)
+            __hip_atomic_store((unsigned long long *)(flow + row), (unsigned long long)__double_as_longlong(v),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else if (FWD) flow[row] = v;
+          if (!FWD) zout[row] = v;
+        }
+      }
+      pub = have;
+      __hip_atomic_store(published, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return;
+  }
+
+  if (wave > 1) {  // ---- loaders
     const int nGroups = (m + GROUP - 1) / GROUP;
-    for (int g = wave - 1; g < nGroups; g += FLOW_LOADERS) {
-      const int need = GROUP * (g + 1) - NSR;  // rows the consumer must be done with
+    for (int g = wave - 2; g < nGroups; g += FLOW_LOADERS) {
+      const int need = GROUP * (g + 1) - NSR;  // rows the publisher must be done with
       if (need > 0) {
         int spins = 0;
-        while (__hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+        while (__hip_atomic_load(published, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
           if (__hip_atomic_load(abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
           if (++spins >= FLOW_MAX_LDS_SPIN) {
             __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -273,13 +325,14 @@ __global__ __launch_bounds__(64 * (1 + FLOW_LOADERS)) void k_flow_sweep(FlowView
           __builtin_amdgcn_s_sleep(2);
         }
       }
-      int row[GB], cd[GB][W];
+      int row[GB], raw[GB], cd[GB][W];
       double av[GB][W], rr[GB], dd[GB];
 #pragma unroll
       for (int b = 0; b < GB; ++b) {
         const int q = g * GROUP + b * 64 + lane;
         const bool ok = q < m;
-        row[b] = ok ? F.rowOf[(size_t)C.rowOff + q] : -1;
+        raw[b] = ok ? F.rowOf[(size_t)C.rowOff + q] : 0;
+        row[b] = ok ? (raw[b] & FLOW_ROW_MASK) : -1;
 #pragma unroll
         for (int k = 0; k < W; ++k)
           if (k < w && ok) {
@@ -300,14 +353,23 @@ __global__ __launch_bounds__(64 * (1 + FLOW_LOADERS)) void k_flow_sweep(FlowView
           const int slot = (g * GROUP + b * 64 + lane) % NSR;
           sR[slot] = rr[b];
           sDV[slot] = dd[b];
-          sRow[slot] = row[b];
+          sRow[slot] = raw[b];
+          int g0 = dummyRow, g1 = dummyRow, ne = 0;
 #pragma unroll
           for (int k = 0; k < W; ++k)
             if (k < w) {
               sC[k * NSR + slot] = cd[b][k];
               sA[k * NSR + slot] = av[b][k];
+              if (cd[b][k] < 0 && cd[b][k] != FLOW_PAD) {
+                if (ne == 0) g0 = ~cd[b][k];
+                if (ne == 1) g1 = ~cd[b][k];
+                ++ne;
+              }
             }
-          ((unsigned long long *)rearm)[row[b]] = FLOW_SENT;
+          sG0[slot] = g0;
+          sG1[slot] = g1;
+          // (only the rows that the other sweep publishes to other chunks are ever polled)
+          if (raw[b] & FLOW_REARM) ((unsigned long long *)rearm)[row[b]] = FLOW_SENT;
         }
       __hip_atomic_store(&ready[g % NG], g + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -316,10 +378,16 @@ __global__ __launch_bounds__(64 * (1 + FLOW_LOADERS)) void k_flow_sweep(FlowView
 
   // ---- consumer
   const int nSteps = C.nSteps;
-  auto off = [&](int s) { return __builtin_amdgcn_readfirstlane(sSteps[s]); };
-  int readyUpTo = 0;
+  // first rows of steps vbase .. vbase + 63, one per lane (uniform reads without a memory access)
+  int vbase = 0;
+  int vstep = sSteps[min(lane, nSteps)];
+  auto off = [&](int s) { return __builtin_amdgcn_readlane(vstep, min(s, nSteps) - vbase); };
+  int readyUpTo = 0, readyRows = 0;
   bool dead = false;
+  long long trPollTicks = 0, trPolls = 0, trEnsureTicks = 0, trRingTicks = 0;  // NG_SGS_TRACE only
   auto ensure = [&](int rowsEnd) {  // rows [0, rowsEnd) are in the staging ring
+    if (__builtin_expect(rowsEnd <= readyRows, 1)) return;  // (the loops below stay off the usual path)
+    const long long trT0 = F.trace ? wall_clock64() : 0;
     const int ng = (rowsEnd + GROUP - 1) / GROUP;
     while (readyUpTo < ng) {
       int spins = 0;
@@ -334,80 +402,132 @@ __global__ __launch_bounds__(64 * (1 + FLOW_LOADERS)) void k_flow_sweep(FlowView
       }
       ++readyUpTo;
     }
+    readyRows = readyUpTo * GROUP;
+    if (F.trace) trEnsureTicks += wall_clock64() - trT0;
   };
   const double sentD = __longlong_as_double((long long)FLOW_SENT);
-  // values of other chunks for step s, asked for D steps ahead: the first two external entries of
-  // every row (always two loads, so that the compiler can count what is in flight)
-  // Steps past the end are empty: the two loads are issued on EVERY path, or the compiler, which
-  // counts what is in flight per path, would wait for all of them at every step.
+  // Values of other chunks for step s, asked for D steps ahead: the first two external entries of
+  // every row.  The two loads are issued on EVERY path, steps past the end and rows without such
+  // an entry included (they read flow[0] and never look at the result), and the loaded registers
+  // are not touched before their step: the compiler counts what is in flight per path, and would
+  // otherwise wait for all of it at every step.  For the same reason the consumer issues no other
+  // vector-memory load: step offsets and rows come from LDS.
   auto prefetch = [&](int s, double &e0, double &e1) {
-    const int p0 = off(min(s, nSteps)), p1 = off(min(s + 1, nSteps));
+    const int p0 = off(s), p1 = off(s + 1);
     ensure(p1);
-    int g0 = -1, g1 = -1;
+    int g0 = dummyRow, g1 = dummyRow;
     const int q = p0 + lane;
     if (!dead && q < p1) {
       const int slot = q % NSR;
-      for (int k = 0; k < w; ++k) {
-        const int c = sC[k * NSR + slot];
-        if (c == FLOW_PAD) break;
-        if (c < 0) {
-          if (g0 < 0) g0 = ~c;
-          else { g1 = ~c; break; }
-        }
-      }
+      g0 = sG0[slot];
+      g1 = sG1[slot];
     }
-    // (rows without such an entry read flow[0] and never look at the result: no select here, the
-    // loaded registers must not be touched before their step)
-    e0 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + max(g0, 0)),
+    e0 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + g0),
                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    e1 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + max(g1, 0)),
+    e1 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + g1),
                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   };
-  auto consume = [&](int s, double e0, double e1) {
+  // a step's rows out of the staging ring: read one step ahead, off the chain of dependent values
+  struct Stage {
+    int c[W];
+    double a[W], own, dv;
+    int q, beg, end;
+    bool act;
+  };
+  auto load_stage = [&](int s, Stage &S) {
     const int s0 = off(s), s1 = off(s + 1);
     ensure(s1);
-    if (dead) return;
-    const int q = s0 + lane;
-    if (q < s1) {
-      const int slot = q % NSR;
-      const double own = sR[slot];
-      double acc = FWD ? own : 0.0;
+    S.q = s0 + lane;
+    S.beg = s0;
+    S.end = s1;
+    S.act = !dead && S.q < s1;
+    if (S.act) {
+      const int slot = S.q % NSR;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        S.c[k] = k < w ? sC[k * NSR + slot] : FLOW_PAD;
+        S.a[k] = k < w ? sA[k * NSR + slot] : 0.0;
+      }
+      S.own = sR[slot];
+      S.dv = sDV[slot];
+    }
+  };
+  auto compute = [&](const Stage &S, double e0, double e1) {
+    if (S.act) {
+      double tv[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) tv[k] = S.c[k] > 0 ? tring[(S.q - S.c[k]) & F.ringMask] : 0.0;
+      double acc = FWD ? S.own : 0.0;
       int e = 0;
-      for (int k = 0; k < w; ++k) {
-        const int c = sC[k * NSR + slot];
-        if (c == FLOW_PAD) break;
-        double v;
-        if (c > 0) v = tring[(q - c) & F.ringMask];
-        else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        if (S.c[k] == FLOW_PAD) continue;
+        double v = tv[k];
+        if (S.c[k] < 0) {
           v = e == 0 ? e0 : e == 1 ? e1 : sentD;
           ++e;
-          if ((unsigned long long)__double_as_longlong(v) == FLOW_SENT) v = flow_poll(flow + ~c, err);
+          if ((unsigned long long)__double_as_longlong(v) == FLOW_SENT) {
+            const long long trT0 = F.trace ? wall_clock64() : 0;
+            v = flow_poll(flow + ~S.c[k], err);
+            if (F.trace) { trPollTicks += wall_clock64() - trT0; ++trPolls; }
+          }
         }
-        const double a = sA[k * NSR + slot];
-        acc = FWD ? acc - a * v : acc + a * v;
+        acc = FWD ? acc - S.a[k] * v : acc + S.a[k] * v;
       }
-      const double out = FWD ? acc * sDV[slot] : own - acc * sDV[slot];
-      const int row = sRow[slot];
-      tring[q & F.ringMask] = out;
-      __hip_atomic_store((unsigned long long *)(flow + row), (unsigned long long)__double_as_longlong(out),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!FWD) zout[row] = out;
+      tring[S.q & F.ringMask] = FWD ? acc * S.dv : S.own - acc * S.dv;
     }
-    __hip_atomic_store(consumed, s1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  // a ring slot is written again `ring` rows later: the publisher must have stored the old row by then
+  int pubSeen = 0;
+  auto ring_free = [&](int rowsEnd) {
+    if (__builtin_expect(rowsEnd - ring <= pubSeen, 1)) return;
+    const long long trT0 = F.trace ? wall_clock64() : 0;
+    int spins = 0;
+    while ((pubSeen = __hip_atomic_load(published, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < rowsEnd - ring) {
+      if (__hip_atomic_load(abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) || ++spins >= FLOW_MAX_LDS_SPIN) {
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(abortFlag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        dead = true;
+        return;
+      }
+    }
+    if (F.trace) trRingTicks += wall_clock64() - trT0;
   };
 
+  static_assert(D % 2 == 0, "the two stages alternate inside the unrolled round");
   double ex0[D], ex1[D];
+  Stage st[2];
+  if (F.trace && lane == 0) F.trace[8 * blockIdx.x] = wall_clock64();
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-    prefetch(j, ex0[j], ex1[j]);
-  }
+  for (int j = 0; j < D; ++j) prefetch(j, ex0[j], ex1[j]);
+  load_stage(0, st[0]);
   for (int sb = 0; sb < nSteps && !dead; sb += D) {
+    if (sb + 2 * D + 1 - vbase > 63) {  // this round reads the offsets of steps sb .. sb + 2 D + 1
+      vbase = sb;
+      vstep = sSteps[min(sb + lane, nSteps)];
+    }
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       const int s = sb + j;
-      if (s < nSteps) consume(s, ex0[j], ex1[j]);
+      load_stage(s + 1, st[(j + 1) & 1]);
+      ring_free(st[j & 1].end);
+      if (!dead) compute(st[j & 1], ex0[j], ex1[j]);
+      if (F.trace && lane == 0 && s < 1024 && (blockIdx.x == 5 || blockIdx.x == gridDim.x / 2 + 5))
+        F.trace[8 * gridDim.x + (blockIdx.x == 5 ? 0 : 2048) + 2 * s] = wall_clock64(),
+        F.trace[8 * gridDim.x + (blockIdx.x == 5 ? 0 : 2048) + 2 * s + 1] = trPolls;
+      if (s < nSteps && !dead)  // hands the step's rows to the publisher
+        __hip_atomic_store(consumed, st[j & 1].end, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       prefetch(s + D, ex0[j], ex1[j]);
     }
+    if (F.trace && lane == 0 && sb == 0) F.trace[8 * blockIdx.x + 1] = wall_clock64();
+    if (F.trace && lane == 0 && sb <= nSteps / 2) F.trace[8 * blockIdx.x + 2] = wall_clock64();
+  }
+  if (F.trace && lane == 0) {
+    F.trace[8 * blockIdx.x + 3] = wall_clock64();
+    F.trace[8 * blockIdx.x + 4] = trPollTicks;
+    F.trace[8 * blockIdx.x + 5] = trPolls;
+    F.trace[8 * blockIdx.x + 6] = trEnsureTicks;
+    F.trace[8 * blockIdx.x + 7] = trRingTicks;
   }
 }
 
@@ -568,13 +688,40 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *f
   F.ringMask = fd.ring - 1;
   F.wLds = std::max(fd.wMax, 1);
   F.maxSteps = fd.maxSteps;
+  F.trace = nullptr;
+  const char *tracePath = getenv("NG_SGS_TRACE");
+  if (tracePath) {
+    NG_HIP(hipMalloc(&F.trace, sizeof(long long) * (8 * (size_t)fd.nChunks + 4096)));
+    NG_HIP(hipMemsetAsync(F.trace, 0, sizeof(long long) * (8 * (size_t)fd.nChunks + 4096), h->stream));
+  }
   int *err = (int *)(h->dReduce + REDUCE_CAP) + 2;
-  const dim3 block(64 * (1 + FLOW_LOADERS));
+  const dim3 block(64 * (2 + FLOW_LOADERS));
   if (fd.depth == 8)
     k_flow_sweep<FWD, 8, 4, 4><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
+  else if (fd.depth == 4)
+    k_flow_sweep<FWD, 4, 4, 4><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
+  else if (fd.wMax <= 4)
+    k_flow_sweep<FWD, 2, 4, 4><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
   else
     k_flow_sweep<FWD, 2, 16, 1><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
   NG_HIP(hipGetLastError());
+  if (tracePath) {  // development aid: the last sweep's per-chunk clocks (100 MHz ticks), one file per direction
+    std::vector<long long> t((size_t)fd.nChunks * 8 + 4096);
+    NG_HIP(hipStreamSynchronize(h->stream));
+    NG_HIP(hipMemcpy(t.data(), F.trace, sizeof(long long) * t.size(), hipMemcpyDeviceToHost));
+    (void)hipFree(F.trace);
+    FILE *f = t[3] ? fopen((std::string(tracePath) + (FWD ? ".fwd" : ".bwd")).c_str(), "w") : nullptr;  // (a sweep skipped on the device's done flag leaves zeros)
+    if (f) {
+      for (int c = 0; c < fd.nChunks; ++c)
+        fprintf(f, "%d %lld %lld %lld %lld %lld %lld %lld %lld\n", c, t[8 * c], t[8 * c + 1], t[8 * c + 2], t[8 * c + 3],
+                t[8 * c + 4], t[8 * c + 5], t[8 * c + 6], t[8 * c + 7]);
+      fclose(f);
+      if (FILE *f2 = fopen((std::string(tracePath) + (FWD ? ".fwd" : ".bwd") + ".steps").c_str(), "w")) {
+        for (int i = 0; i < 4096; ++i) fprintf(f2, "%lld\n", t[8 * (size_t)fd.nChunks + i]);
+        fclose(f2);
+      }
+    }
+  }
   return NALU_GPU_OK;
 }
 
@@ -607,11 +754,16 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     nalu_gpu_linsys::FlowDir &fd = h->flow[dir];
     const FlowSchedule &s = S[dir];
     int ring = 64;
-    while (ring < s.maxLookback + FLOW_STEP) ring *= 2;
-    if (ring > 4096 || s.wMax > 16) return NALU_GPU_OK;
+    while (ring < s.maxLookback + FLOW_STEP + FLOW_PUB_WINDOW) ring *= 2;
+    if (ring > 8192 || s.wMax > 16) return NALU_GPU_OK;
     const int wl = std::max(s.wMax, 1);
-    fd.depth = s.wMax <= 4 ? 8 : 2;
-    fd.ldsBytes = fd.depth == 8 ? FlowA::lds_bytes(ring, wl, s.maxSteps) : FlowB::lds_bytes(ring, wl, s.maxSteps);
+    int depth = getenv("NG_SGS_DEPTH") ? atoi(getenv("NG_SGS_DEPTH")) : 8;
+    depth = depth >= 8 ? 8 : depth >= 4 ? 4 : 2;
+    fd.depth = s.wMax <= 4 ? depth : 2;
+    fd.ldsBytes = s.wMax > 4       ? FlowB::lds_bytes(ring, wl, s.maxSteps)
+                  : fd.depth == 8 ? FlowA::lds_bytes(ring, wl, s.maxSteps)
+                  : fd.depth == 4 ? FlowCfg<4, 4, 4>::lds_bytes(ring, wl, s.maxSteps)
+                                  : FlowCfg<2, 4, 4>::lds_bytes(ring, wl, s.maxSteps);
     if (fd.ldsBytes > FLOW_MAX_LDS) return NALU_GPU_OK;
     fd.ring = ring;
     fd.wMax = s.wMax;
@@ -619,13 +771,24 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     fd.nChunks = (int)s.chunks.size();
     fd.nEnt = (long long)s.code.size();
   }
+  {  // a sweep resets, for the next sweep, the rows that sweep polls: the visible rows of the other schedule
+    std::vector<char> vis[2];
+    for (int dir = 0; dir < 2; ++dir) {
+      vis[dir].assign((size_t)n, 0);
+      for (int r : S[dir].rowOf)
+        if ((unsigned)r & FLOW_VISIBLE) vis[dir][(size_t)(r & FLOW_ROW_MASK)] = 1;
+    }
+    for (int dir = 0; dir < 2; ++dir)
+      for (int &r : S[dir].rowOf)
+        if (vis[1 - dir][(size_t)(r & FLOW_ROW_MASK)]) r |= FLOW_REARM;
+  }
   for (int dir = 0; dir < 2; ++dir) {
     nalu_gpu_linsys::FlowDir &fd = h->flow[dir];
     FlowSchedule &s = S[dir];
     // CSR entry -> position of its value in the SELL matrix
     for (const FlowChunk &C : s.chunks)
       for (int q = 0; q < C.m; ++q) {
-        const int i = s.rowOf[(size_t)C.rowOff + q];
+        const int i = s.rowOf[(size_t)C.rowOff + q] & FLOW_ROW_MASK;
         const long long so = h->hSliceOff[i / SELL_C] + i % SELL_C;
         for (int k = 0; k < C.w; ++k) {
           long long &e = s.src[(size_t)(C.entOff + (long long)k * C.m + q)];
@@ -646,6 +809,10 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
   NG_HIP(hipMalloc(&h->dFlowZ, sizeof(double) * (size_t)n));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 2, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 2, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   h->flowTiled = T.tiled;

@@ -26,6 +26,7 @@ namespace nalu_gpu {
 
 constexpr int FLOW_PAD = INT_MIN;
 constexpr int FLOW_STEP = 64;  // rows per step: one wavefront
+constexpr unsigned FLOW_VISIBLE = 0x80000000u;
 
 struct FlowChunk {   // 32 bytes, read by the device
   long long entOff;  // entry k of compact row q of the chunk: entOff + k * m + q
@@ -39,7 +40,8 @@ struct FlowChunk {   // 32 bytes, read by the device
 
 struct FlowSchedule {
   std::vector<FlowChunk> chunks;  // in processing (= dispatch) order
-  std::vector<int> rowOf;         // n: matrix row of every compact row
+  std::vector<int> rowOf;         // n: matrix row of every compact row; bit 31 (FLOW_VISIBLE): the row is read by
+                                  // other chunks, its value has to be published as it is computed
   std::vector<int> code;          // entries
   std::vector<long long> src;     // entries: CSR entry index the value comes from (-1: pad)
   std::vector<int> steps;
@@ -67,6 +69,7 @@ inline std::string flow_build(int n, const int64_t *rowPtr, const int *colIdx, c
   }
   auto is_dep = [&](int i, int c) { return fwd ? c < i : (c > i && c < n); };
   std::vector<int> lvl((size_t)n, 0), pos((size_t)n, 0);
+  std::vector<char> visible((size_t)n, 0);
   S.rowOf.resize((size_t)n);
   S.chunks.reserve((size_t)nChunks);
   long long entTotal = 0;
@@ -131,6 +134,7 @@ inline std::string flow_build(int n, const int64_t *rowPtr, const int *colIdx, c
           S.maxLookback = std::max(S.maxLookback, back);
         } else {
           S.code[idx] = ~col;
+          visible[col] = 1;
           ++S.nExternal;
         }
         ++kk;
@@ -142,6 +146,8 @@ inline std::string flow_build(int n, const int64_t *rowPtr, const int *colIdx, c
     S.chunks.push_back(C);
   }
   if (S.code.empty()) { S.code.push_back(FLOW_PAD); S.src.push_back(-1); }
+  for (int &r : S.rowOf)
+    if (visible[r]) r = (int)((unsigned)r | FLOW_VISIBLE);
   return std::string();
 }
 
@@ -149,7 +155,8 @@ inline std::string flow_build(int n, const int64_t *rowPtr, const int *colIdx, c
 // rows in the forward sweep, on higher rows in the backward one).  On a lattice-numbered mesh
 // (row = x + Q y + P z: the three dominant lower offsets are 1 < Q < P with Q | P) tiles of
 // By lines x Bz planes put most y and z dependencies inside the chunk and leave
-// ny/By + nz/Bz chunk-to-chunk hops on the critical path instead of ny + nz.
+// ny/By + nz/Bz chunk-to-chunk hops on the critical path instead of ny + nz.  (Some tiles may be
+// empty when n is not a multiple of P: flow_build skips them.)
 struct FlowTiling {
   bool tiled = false;
   int Q = 0, P = 0, By = 0, Bz = 0;
@@ -200,13 +207,23 @@ inline FlowTiling flow_chunking(int n, const int64_t *rowPtr, const int *colIdx,
   if (P > 0) {
     const long long blockRows = (long long)By * Q;
     const int nYb = (int)((P + blockRows - 1) / blockRows);
+    // tiles in anti-diagonal order (yb + zb, then zb): a tile's producers (yb - 1, zb) and
+    // (yb, zb - 1) come earlier, and the workgroups resident at any time are the ones whose turn
+    // is next (a z-major order would fill the chip with tiles that wait for most of the sweep)
+    const int nZb = (n - 1) / P / Bz + 1;
+    std::vector<int> order((size_t)nZb * nYb);
+    {
+      int next = 0;
+      for (int d = 0; d <= nZb + nYb - 2; ++d)
+        for (int zb = std::max(0, d - (nYb - 1)); zb <= std::min(d, nZb - 1); ++zb) order[(size_t)zb * nYb + (d - zb)] = next++;
+    }
     for (int i = 0; i < n; ++i) {
-      const int zb = i / P, within = i % P;
-      chunkOf[i] = (zb / Bz) * nYb + (int)(within / blockRows);
+      const int zb = i / P / Bz, within = i % P;
+      chunkOf[i] = order[(size_t)zb * nYb + (int)(within / blockRows)];
     }
     T.tiled = true;
     T.Q = Q; T.P = P; T.By = By; T.Bz = Bz;
-    T.nChunks = ((n - 1) / P / Bz + 1) * nYb;
+    T.nChunks = nZb * nYb;
   } else {
     for (int i = 0; i < n; ++i) chunkOf[i] = i / chunkRows;
     T.nChunks = n ? (n - 1) / chunkRows + 1 : 0;

@@ -99,7 +99,7 @@ static int check(const char *name, const Csr &A, int chunkRows, int By, int Bz)
     int ring = 64;
     while (ring < S.maxLookback + FLOW_STEP) ring *= 2;
     const double NANV = std::nan("");
-    std::vector<double> flow((size_t)n, NANV), ringBuf((size_t)ring);
+    std::vector<double> flow((size_t)n, NANV), all((size_t)n, NANV), ringBuf((size_t)ring);
     const std::vector<double> &in = fwd ? r : tRef;
     long long notReady = 0, rowsSeen = 0;
     for (const FlowChunk &C : S.chunks) {
@@ -108,7 +108,7 @@ static int check(const char *name, const Csr &A, int chunkRows, int By, int Bz)
         if (s1 - s0 > FLOW_STEP || s1 <= s0) { printf("%s: bad step %d..%d\n", name, s0, s1); return 1; }
         std::vector<double> out((size_t)(s1 - s0));
         for (int q = s0; q < s1; ++q) {
-          const int row = S.rowOf[(size_t)C.rowOff + q];
+          const int row = S.rowOf[(size_t)C.rowOff + q] & 0x7fffffff;
           double acc = fwd ? in[row] : 0.0;
           for (int k = 0; k < C.w; ++k) {
             const size_t idx = (size_t)(C.entOff + (long long)k * C.m + q);
@@ -130,13 +130,16 @@ static int check(const char *name, const Csr &A, int chunkRows, int By, int Bz)
         }
         for (int q = s0; q < s1; ++q) {  // a step's rows are independent: written after all were read
           ringBuf[(size_t)(q & (ring - 1))] = out[(size_t)(q - s0)];
-          flow[(size_t)S.rowOf[(size_t)C.rowOff + q]] = out[(size_t)(q - s0)];
+          // only the rows marked visible reach other chunks
+          if ((unsigned)S.rowOf[(size_t)C.rowOff + q] & FLOW_VISIBLE)
+            flow[(size_t)(S.rowOf[(size_t)C.rowOff + q] & 0x7fffffff)] = out[(size_t)(q - s0)];
+          all[(size_t)(S.rowOf[(size_t)C.rowOff + q] & 0x7fffffff)] = out[(size_t)(q - s0)];
         }
       }
     }
     const std::vector<double> &ref = fwd ? tRef : zRef;
     long long diff = 0;
-    for (int i = 0; i < n; ++i) diff += std::memcmp(&flow[i], &ref[i], 8) != 0;
+    for (int i = 0; i < n; ++i) diff += std::memcmp(&all[i], &ref[i], 8) != 0;
     printf("%-22s %s: %s chunks %zu wMax %d lookback %d ring %d maxSteps %d external %lld  rows %lld notReady %lld "
            "mismatches %lld\n", name, fwd ? "fwd" : "bwd", T.tiled ? "tiled" : "contiguous", S.chunks.size(), S.wMax,
            S.maxLookback, ring, S.maxSteps, S.nExternal, rowsSeen, notReady, diff);
