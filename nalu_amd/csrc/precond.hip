@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_mc_sweep(SellView A, const int *__restr
 // 8-byte agent-scope store publishes a value, ~0.6 us from store to a polling load on MI355X,
 // scripts/flowbench.hip) -- the consumer asks for them D steps ahead and only spins when one is
 // still missing at its step.  Wave 1 (the publisher) stores the computed values from the LDS ring
-// to memory; waves 2-3 (the loaders) stream the chunk's rows, D + 2 steps or more ahead, into an
+// to memory; waves 2-4 (the loaders) stream the chunk's rows, D + 2 steps or more ahead, into an
 // LDS staging ring: matrix values, entry codes, r, 1/d, row numbers.
 // Every spin is bounded; a wave that gives up sets *err, after which no wave waits any more, the
 // grid drains and nalu_gpu_solve reports the failure.  Workgroups only wait for chunks earlier in
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void k_mc_sweep(SellView A, const int *__restr
 constexpr unsigned long long FLOW_SENT = ~0ull;
 constexpr int FLOW_REARM = 0x40000000;  // rowOf bit 30 (set in ensure_sgs_flow): visible in the OTHER sweep's schedule
 constexpr int FLOW_ROW_MASK = 0x3fffffff;
-constexpr int FLOW_LOADERS = 2;       // waves 2 and 3 (wave 0: consumer, wave 1: publisher)
-constexpr int FLOW_PUB_WINDOW = 512;  // rows the publisher may lag behind the consumer
+constexpr int FLOW_LOADERS = 3;       // waves 2 to 4 (wave 0: consumer, wave 1: publisher)
+constexpr int FLOW_PUB_WINDOW = 256;  // rows the publisher may lag behind the consumer
 constexpr int FLOW_MAX_POLL = 1 << 20;      // ~0.6 s of polling one value
 constexpr int FLOW_MAX_LDS_SPIN = 1 << 24;  // loaders <-> consumer inside one workgroup
 
@@ -194,21 +194,24 @@ struct FlowView {
   const int *rowOf, *code, *steps;
   const double *val;
   int ringMask;  // LDS ring of in-chunk values: ring - 1, ring >= largest lookback + 64
-  int wLds;      // entries per row the staging ring is laid out for
   int maxSteps;  // most steps of any chunk (the step offsets of a chunk are copied to LDS)
   long long *trace;  // development aid (NG_SGS_TRACE): per chunk, clock at start / after the first step / at the end
 };
 
-// D: steps of look-ahead for values of other chunks; W: entries per row at most; GB: batches of
-// 64 rows a loader wave has in flight; NSR: rows of the staging ring
+// D: steps of look-ahead for values of other chunks; W: entries per row at most (a multiple of 4);
+// GB: batches of 64 rows a loader wave has in flight; NSR: rows of the staging ring (a power of two:
+// D steps of look-ahead + a loader group + what the publisher may still hold)
+constexpr int flow_pow2(int v) { int p = 64; while (p < v) p *= 2; return p; }
 template <int D, int W, int GB>
 struct FlowCfg {
   static constexpr int GROUP = GB * 64;
-  static constexpr int NSR = (D + 2 + GB + GB - 1) / GB * GROUP;
+  static constexpr int NSR = flow_pow2(D * 64 + GROUP + 64);
   static constexpr int NG = NSR / GROUP;
-  static size_t lds_bytes(int ring, int w, int maxSteps)
+  // per staged row: W values, W codes, W/4 packed ring slots, r, 1/d, row, meta, two rows of other chunks
+  static constexpr int ROW_BYTES = 8 * W + 4 * W + 2 * W + 8 + 8 + 4 + 4 + 8;
+  static size_t lds_bytes(int ring, int maxSteps)
   {
-    return 8u * (size_t)ring + (size_t)NSR * (28u + 12u * (size_t)w) + 4u * (size_t)(NG + 4 + maxSteps + 2);
+    return 8u * (size_t)(ring + 2) + (size_t)NSR * ROW_BYTES + 4u * (size_t)(NG + 4 + maxSteps + 2);
   }
 };
 
@@ -236,6 +239,12 @@ __device__ __forceinline__ double flow_poll(const double *p, int *err)
 // FWD: flow_i = (in_i - sum_{c<i} a_ic flow_c) dinv_i              (in = r, flow = t)
 // else: flow_i = in_i - (sum_{i<c<n} a_ic flow_c) dinv_i, zout_i = flow_i   (in = t, flow = z)
 // rearm: the vector the NEXT sweep polls; the loaders reset this chunk's rows of it to "not computed"
+//
+// The consumer's step is the unit of the sweep's critical path (~3 n steps on an n^3 lattice, plus
+// the hops between chunks), so everything that can be is done by the other waves: the loaders turn
+// the entry codes into LDS ring slots (a slot that always holds 0.0 for entries of other chunks and
+// for padding), count and locate the entries of other chunks, and pad every row to W entries, so that
+// the consumer's usual path has no data-dependent branch.
 template <bool FWD, int D, int W, int GB>
 __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView F, const int *__restrict__ done,
                                                                         const double *in,
@@ -243,26 +252,28 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
                                                                         double *zout, double *rearm, int *err)
 {
   using Cfg = FlowCfg<D, W, GB>;
-  constexpr int NSR = Cfg::NSR, NG = Cfg::NG, GROUP = Cfg::GROUP;
+  constexpr int NSR = Cfg::NSR, NG = Cfg::NG, GROUP = Cfg::GROUP, WQ = W / 4;
+  static_assert(W % 4 == 0 && D % 2 == 0, "ring slots are packed four to a word; two stages alternate");
   if (done && *done) return;
   extern __shared__ double flowLds[];
   const int ring = F.ringMask + 1;
-  double *tring = flowLds;
-  double *sR = tring + ring;
-  double *sDV = sR + NSR;
-  double *sA = sDV + NSR;                     // [wLds][NSR]
-  int *sC = (int *)(sA + (size_t)F.wLds * NSR);  // [wLds][NSR]
-  int *sRow = sC + (size_t)F.wLds * NSR;
-  int *sG0 = sRow + NSR;  // rows of the first two entries that belong to other chunks (0: none)
-  int *sG1 = sG0 + NSR;
-  int *ready = sG1 + NSR;  // [NG]: group g staged <=> ready[g % NG] == g + 1
-  int *consumed = ready + NG;      // rows the consumer has computed (their values are in tring)
+  double *tring = flowLds;             // [ring] values of the chunk's last rows, [ring] = 0.0
+  double *sA = tring + ring + 2;       // [W][NSR] matrix values (0.0: padding)
+  double *sR = sA + W * NSR;           // r_i (forward) / t_i (backward)
+  double *sDV = sR + NSR;              // 1 / d_i
+  unsigned long long *sT = (unsigned long long *)(sDV + NSR);  // [WQ][NSR] ring slots of four entries, 16 bits each
+  int2 *sG = (int2 *)(sT + WQ * NSR);  // rows of the first two entries of other chunks (negative: no such entry)
+  int *sC = (int *)(sG + NSR);         // [W][NSR] entry codes (the rare row that has to poll reads them)
+  int *sRow = sC + W * NSR;            // matrix row + FLOW_VISIBLE / FLOW_REARM
+  int *sM = sRow + NSR;                // k0 | k1 << 8 | next << 16: entries of other chunks (first, second: 255 = none; count)
+  int *ready = sM + NSR;               // [NG]: group g staged <=> ready[g % NG] == g + 1
+  int *consumed = ready + NG;          // rows the consumer has computed (their values are in tring)
   int *abortFlag = consumed + 1;
-  int *published = abortFlag + 1;  // rows the publisher has stored: their staging rows and ring slots are free
-  int *sSteps = abortFlag + 3;  // [nSteps + 1]: first row of every step (LDS: the consumer's only vector-memory
-                                // traffic must be its look-ahead loads and its stores, see prefetch below)
+  int *published = abortFlag + 1;      // rows the publisher has stored: their staging rows and ring slots are free
+  int *sSteps = abortFlag + 3;         // [nSteps + 1]: first row of every step
   const FlowChunk C = F.chunks[blockIdx.x];
   if (threadIdx.x < NG + 4) ready[threadIdx.x] = 0;
+  if (threadIdx.x < 2) tring[ring + threadIdx.x] = 0.0;
   for (int i = threadIdx.x; i <= C.nSteps; i += blockDim.x) sSteps[i] = F.steps[C.stepOff + i];
   __syncthreads();
 
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
         const int q = q0 + lane;
         if (q < have) {
           const double v = tring[q & F.ringMask];
-          const int raw = sRow[q % NSR], row = raw & FLOW_ROW_MASK;
+          const int raw = sRow[q & (NSR - 1)], row = raw & FLOW_ROW_MASK;
           // rows that other chunks read are published at once; the rest is only needed after the sweep
           if (raw < 0)
             __hip_atomic_store((unsigned long long *)(flow + row), (unsigned long long)__double_as_longlong(v),
@@ -310,8 +321,42 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
   }
 
   if (wave > 1) {  // ---- loaders
+    // One memory round trip per group of GB x 64 rows: the row numbers of a wave's next group are
+    // loaded with the data of the current one, and all loads are issued before the wave waits for
+    // the ring slots to become free.
     const int nGroups = (m + GROUP - 1) / GROUP;
+    int rawNext[GB];
+#pragma unroll
+    for (int b = 0; b < GB; ++b) {
+      const int q = (wave - 2) * GROUP + b * 64 + lane;
+      rawNext[b] = q < m ? F.rowOf[(size_t)C.rowOff + q] : 0;
+    }
     for (int g = wave - 2; g < nGroups; g += FLOW_LOADERS) {
+      int row[GB], raw[GB], cd[GB][W];
+      double av[GB][W], rr[GB], dd[GB];
+#pragma unroll
+      for (int b = 0; b < GB; ++b) {
+        const int q = g * GROUP + b * 64 + lane;
+        const bool ok = q < m;
+        raw[b] = rawNext[b];
+        row[b] = ok ? (raw[b] & FLOW_ROW_MASK) : -1;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          cd[b][k] = FLOW_PAD;
+          av[b][k] = 0.0;
+          if (k < w && ok) {
+            const size_t idx = (size_t)(C.entOff + (long long)k * m + q);
+            cd[b][k] = F.code[idx];
+            av[b][k] = F.val[idx];
+          }
+        }
+        if (ok) {
+          rr[b] = in[row[b]];
+          dd[b] = dinv[row[b]];
+        }
+        const int qn = q + FLOW_LOADERS * GROUP;
+        rawNext[b] = qn < m ? F.rowOf[(size_t)C.rowOff + qn] : 0;
+      }
       const int need = GROUP * (g + 1) - NSR;  // rows the publisher must be done with
       if (need > 0) {
         int spins = 0;
@@ -325,49 +370,35 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
           __builtin_amdgcn_s_sleep(2);
         }
       }
-      int row[GB], raw[GB], cd[GB][W];
-      double av[GB][W], rr[GB], dd[GB];
-#pragma unroll
-      for (int b = 0; b < GB; ++b) {
-        const int q = g * GROUP + b * 64 + lane;
-        const bool ok = q < m;
-        raw[b] = ok ? F.rowOf[(size_t)C.rowOff + q] : 0;
-        row[b] = ok ? (raw[b] & FLOW_ROW_MASK) : -1;
-#pragma unroll
-        for (int k = 0; k < W; ++k)
-          if (k < w && ok) {
-            const size_t idx = (size_t)(C.entOff + (long long)k * m + q);
-            cd[b][k] = F.code[idx];
-            av[b][k] = F.val[idx];
-          }
-      }
 #pragma unroll
       for (int b = 0; b < GB; ++b)
         if (row[b] >= 0) {
-          rr[b] = in[row[b]];
-          dd[b] = dinv[row[b]];
-        }
-#pragma unroll
-      for (int b = 0; b < GB; ++b)
-        if (row[b] >= 0) {
-          const int slot = (g * GROUP + b * 64 + lane) % NSR;
+          const int q = g * GROUP + b * 64 + lane;
+          const int slot = q & (NSR - 1);
           sR[slot] = rr[b];
           sDV[slot] = dd[b];
           sRow[slot] = raw[b];
-          int g0 = dummyRow, g1 = dummyRow, ne = 0;
+          int g0 = dummyRow | (int)0x80000000, g1 = g0, ne = 0, k0 = 255, k1 = 255;
+          unsigned long long packed[WQ];
 #pragma unroll
-          for (int k = 0; k < W; ++k)
-            if (k < w) {
-              sC[k * NSR + slot] = cd[b][k];
-              sA[k * NSR + slot] = av[b][k];
-              if (cd[b][k] < 0 && cd[b][k] != FLOW_PAD) {
-                if (ne == 0) g0 = ~cd[b][k];
-                if (ne == 1) g1 = ~cd[b][k];
-                ++ne;
-              }
+          for (int k = 0; k < W; ++k) {
+            const int c = cd[b][k];
+            if (c == FLOW_PAD) av[b][k] = 0.0;  // (the schedule's padding carries no value)
+            sC[k * NSR + slot] = c;
+            sA[k * NSR + slot] = av[b][k];
+            const unsigned ts = c > 0 ? (unsigned)((q - c) & F.ringMask) : (unsigned)ring;  // ring: the 0.0 slot
+            if (k % 4 == 0) packed[k / 4] = 0;
+            packed[k / 4] |= (unsigned long long)ts << (16 * (k % 4));
+            if (c < 0 && c != FLOW_PAD) {
+              if (ne == 0) { g0 = ~c; k0 = k; }
+              if (ne == 1) { g1 = ~c; k1 = k; }
+              ++ne;
             }
-          sG0[slot] = g0;
-          sG1[slot] = g1;
+          }
+#pragma unroll
+          for (int j = 0; j < WQ; ++j) sT[j * NSR + slot] = packed[j];
+          sG[slot] = make_int2(g0, g1);
+          sM[slot] = k0 | (k1 << 8) | (ne << 16);
           // (only the rows that the other sweep publishes to other chunks are ever polled)
           if (raw[b] & FLOW_REARM) ((unsigned long long *)rearm)[row[b]] = FLOW_SENT;
         }
@@ -405,77 +436,100 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
     readyRows = readyUpTo * GROUP;
     if (F.trace) trEnsureTicks += wall_clock64() - trT0;
   };
-  const double sentD = __longlong_as_double((long long)FLOW_SENT);
+  auto is_sent = [](double v) { return (unsigned long long)__double_as_longlong(v) == FLOW_SENT; };
   // Values of other chunks for step s, asked for D steps ahead: the first two external entries of
   // every row.  The two loads are issued on EVERY path, steps past the end and rows without such
-  // an entry included (they read flow[0] and never look at the result), and the loaded registers
-  // are not touched before their step: the compiler counts what is in flight per path, and would
-  // otherwise wait for all of it at every step.  For the same reason the consumer issues no other
-  // vector-memory load: step offsets and rows come from LDS.
+  // an entry included (they read a row of this chunk and never look at the result), and the loaded
+  // registers are not touched before their step: the compiler counts what is in flight per path, and
+  // would otherwise wait for all of it at every step.  For the same reason the consumer issues no
+  // other vector-memory operation: step offsets and rows come from LDS, the publisher stores.
   auto prefetch = [&](int s, double &e0, double &e1) {
     const int p0 = off(s), p1 = off(s + 1);
     ensure(p1);
-    int g0 = dummyRow, g1 = dummyRow;
+    int2 g = make_int2(dummyRow, dummyRow);
     const int q = p0 + lane;
-    if (!dead && q < p1) {
-      const int slot = q % NSR;
-      g0 = sG0[slot];
-      g1 = sG1[slot];
-    }
-    e0 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + g0),
+    if (!dead && q < p1) g = sG[q & (NSR - 1)];
+    e0 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + (g.x & 0x7fffffff)),
                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    e1 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + g1),
+    e1 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + (g.y & 0x7fffffff)),
                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   };
   // a step's rows out of the staging ring: read one step ahead, off the chain of dependent values
   struct Stage {
-    int c[W];
+    unsigned long long t[WQ];
     double a[W], own, dv;
-    int q, beg, end;
+    int q, end, meta;
     bool act;
   };
   auto load_stage = [&](int s, Stage &S) {
     const int s0 = off(s), s1 = off(s + 1);
     ensure(s1);
     S.q = s0 + lane;
-    S.beg = s0;
     S.end = s1;
     S.act = !dead && S.q < s1;
     if (S.act) {
-      const int slot = S.q % NSR;
+      const int slot = S.q & (NSR - 1);
 #pragma unroll
-      for (int k = 0; k < W; ++k) {
-        S.c[k] = k < w ? sC[k * NSR + slot] : FLOW_PAD;
-        S.a[k] = k < w ? sA[k * NSR + slot] : 0.0;
-      }
+      for (int j = 0; j < WQ; ++j) S.t[j] = sT[j * NSR + slot];
+#pragma unroll
+      for (int k = 0; k < W; ++k) S.a[k] = sA[k * NSR + slot];
       S.own = sR[slot];
       S.dv = sDV[slot];
+      S.meta = sM[slot];
     }
+  };
+  // does the row need a value of another chunk that its look-ahead loads did not bring?
+  auto late = [&](const Stage &S, double e0, double e1) {
+    const int k0 = S.meta & 255, k1 = (S.meta >> 8) & 255;
+    return S.act && ((k0 != 255 && is_sent(e0)) || (k1 != 255 && is_sent(e1)));
   };
   auto compute = [&](const Stage &S, double e0, double e1) {
     if (S.act) {
+      const int k0 = S.meta & 255, k1 = (S.meta >> 8) & 255;
       double tv[W];
 #pragma unroll
-      for (int k = 0; k < W; ++k) tv[k] = S.c[k] > 0 ? tring[(S.q - S.c[k]) & F.ringMask] : 0.0;
+      for (int k = 0; k < W; ++k) tv[k] = tring[(S.t[k / 4] >> (16 * (k % 4))) & 0xffff];
       double acc = FWD ? S.own : 0.0;
-      int e = 0;
 #pragma unroll
       for (int k = 0; k < W; ++k) {
-        if (S.c[k] == FLOW_PAD) continue;
-        double v = tv[k];
-        if (S.c[k] < 0) {
-          v = e == 0 ? e0 : e == 1 ? e1 : sentD;
-          ++e;
-          if ((unsigned long long)__double_as_longlong(v) == FLOW_SENT) {
-            const long long trT0 = F.trace ? wall_clock64() : 0;
-            v = flow_poll(flow + ~S.c[k], err);
-            if (F.trace) { trPollTicks += wall_clock64() - trT0; ++trPolls; }
-          }
-        }
+        // (padding: 0.0 * 0.0, which changes neither a forward nor a backward partial sum)
+        const double v = k == k0 ? e0 : k == k1 ? e1 : tv[k];
         acc = FWD ? acc - S.a[k] * v : acc + S.a[k] * v;
+      }
+      if (__builtin_expect(late(S, e0, e1) || (S.meta >> 16) > 2, 0)) {
+        // a value that is still not there (or a third entry of another chunk): the row again, entry by
+        // entry, polling.  One copy of this loop per step: the unrolled round has to stay inside the
+        // instruction cache.
+        const int slot = S.q & (NSR - 1);
+        acc = FWD ? S.own : 0.0;
+#pragma nounroll
+        for (int k = 0; k < w; ++k) {
+          const int c = sC[k * NSR + slot];
+          if (c == FLOW_PAD) break;
+          const double v = c > 0 ? tring[(S.q - c) & F.ringMask] : flow_poll(flow + ~c, err);
+          const double a = sA[k * NSR + slot];
+          acc = FWD ? acc - a * v : acc + a * v;
+        }
       }
       tring[S.q & F.ringMask] = FWD ? acc * S.dv : S.own - acc * S.dv;
     }
+  };
+  // A value asked for D steps ahead was not there yet: this chunk runs right behind a producer.  Going
+  // on step by step would cost a memory round trip per step (and every chunk behind this one would
+  // inherit that pace).  Instead wait until the producers are D - 1 steps further, then ask again for
+  // the values of steps s .. s + D - 1: one wait per D steps.
+  auto recover = [&](int s, auto &&refetch) {
+    const long long trT0 = F.trace ? wall_clock64() : 0;
+    const int p0 = off(s + D - 1), p1 = off(s + D);
+    ensure(p1);
+    const int q = p0 + lane;
+    if (!dead && q < p1) {
+      const int2 g = sG[q & (NSR - 1)];
+      if (g.x >= 0) (void)flow_poll(flow + g.x, err);
+      if (g.y >= 0) (void)flow_poll(flow + g.y, err);
+    }
+    refetch();
+    if (F.trace) { trPollTicks += wall_clock64() - trT0; ++trPolls; }
   };
   // a ring slot is written again `ring` rows later: the publisher must have stored the old row by then
   int pubSeen = 0;
@@ -494,7 +548,6 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
     if (F.trace) trRingTicks += wall_clock64() - trT0;
   };
 
-  static_assert(D % 2 == 0, "the two stages alternate inside the unrolled round");
   double ex0[D], ex1[D];
   Stage st[2];
   if (F.trace && lane == 0) F.trace[8 * blockIdx.x] = wall_clock64();
@@ -511,7 +564,15 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
       const int s = sb + j;
       load_stage(s + 1, st[(j + 1) & 1]);
       ring_free(st[j & 1].end);
-      if (!dead) compute(st[j & 1], ex0[j], ex1[j]);
+      if (!dead) {
+        const Stage &S = st[j & 1];
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(late(S, ex0[j], ex1[j])) != 0, 0))
+          recover(s, [&]() {
+#pragma unroll
+            for (int jj = 0; jj < D; ++jj) prefetch(s + jj, ex0[(j + jj) % D], ex1[(j + jj) % D]);
+          });
+        compute(S, ex0[j], ex1[j]);
+      }
       if (F.trace && lane == 0 && s < 1024 && (blockIdx.x == 5 || blockIdx.x == gridDim.x / 2 + 5))
         F.trace[8 * gridDim.x + (blockIdx.x == 5 ? 0 : 2048) + 2 * s] = wall_clock64(),
         F.trace[8 * gridDim.x + (blockIdx.x == 5 ? 0 : 2048) + 2 * s + 1] = trPolls;
@@ -663,8 +724,12 @@ int sgs_mode()
   if (getenv("NG_SGS_INPLACE") && atoi(getenv("NG_SGS_INPLACE")) != 0) return SGS_INPLACE;
   return SGS_FLOW;
 }
-using FlowA = FlowCfg<8, 4, 4>;   // rows of at most 4 entries a side (7-point graphs): deep look-ahead
-using FlowB = FlowCfg<2, 16, 1>;  // up to 16 (27-point graphs)
+// rows of at most 4 entries a side (7-point graphs): look-ahead of 2, 4 or 8 steps (NG_SGS_DEPTH);
+// up to 16 (27-point graphs): 2 steps
+using FlowA8 = FlowCfg<8, 4, 4>;
+using FlowA4 = FlowCfg<4, 4, 2>;
+using FlowA2 = FlowCfg<2, 4, 2>;
+using FlowB = FlowCfg<2, 16, 1>;
 constexpr size_t FLOW_MAX_LDS = 96 * 1024;
 
 template <class T>
@@ -686,7 +751,6 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *f
   F.steps = fd.dSteps;
   F.val = fd.dVal;
   F.ringMask = fd.ring - 1;
-  F.wLds = std::max(fd.wMax, 1);
   F.maxSteps = fd.maxSteps;
   F.trace = nullptr;
   const char *tracePath = getenv("NG_SGS_TRACE");
@@ -699,9 +763,9 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *f
   if (fd.depth == 8)
     k_flow_sweep<FWD, 8, 4, 4><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
   else if (fd.depth == 4)
-    k_flow_sweep<FWD, 4, 4, 4><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
+    k_flow_sweep<FWD, 4, 4, 2><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
   else if (fd.wMax <= 4)
-    k_flow_sweep<FWD, 2, 4, 4><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
+    k_flow_sweep<FWD, 2, 4, 2><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
   else
     k_flow_sweep<FWD, 2, 16, 1><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
   NG_HIP(hipGetLastError());
@@ -756,14 +820,13 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     int ring = 64;
     while (ring < s.maxLookback + FLOW_STEP + FLOW_PUB_WINDOW) ring *= 2;
     if (ring > 8192 || s.wMax > 16) return NALU_GPU_OK;
-    const int wl = std::max(s.wMax, 1);
-    int depth = getenv("NG_SGS_DEPTH") ? atoi(getenv("NG_SGS_DEPTH")) : 8;
+    int depth = getenv("NG_SGS_DEPTH") ? atoi(getenv("NG_SGS_DEPTH")) : 2;
     depth = depth >= 8 ? 8 : depth >= 4 ? 4 : 2;
     fd.depth = s.wMax <= 4 ? depth : 2;
-    fd.ldsBytes = s.wMax > 4       ? FlowB::lds_bytes(ring, wl, s.maxSteps)
-                  : fd.depth == 8 ? FlowA::lds_bytes(ring, wl, s.maxSteps)
-                  : fd.depth == 4 ? FlowCfg<4, 4, 4>::lds_bytes(ring, wl, s.maxSteps)
-                                  : FlowCfg<2, 4, 4>::lds_bytes(ring, wl, s.maxSteps);
+    fd.ldsBytes = s.wMax > 4       ? FlowB::lds_bytes(ring, s.maxSteps)
+                  : fd.depth == 8 ? FlowA8::lds_bytes(ring, s.maxSteps)
+                  : fd.depth == 4 ? FlowA4::lds_bytes(ring, s.maxSteps)
+                                  : FlowA2::lds_bytes(ring, s.maxSteps);
     if (fd.ldsBytes > FLOW_MAX_LDS) return NALU_GPU_OK;
     fd.ring = ring;
     fd.wMax = s.wMax;
@@ -809,10 +872,10 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
   NG_HIP(hipMalloc(&h->dFlowZ, sizeof(double) * (size_t)n));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
-  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
-  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
-  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
-  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 2, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 2, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   h->flowTiled = T.tiled;
