@@ -573,9 +573,6 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
           });
         compute(S, ex0[j], ex1[j]);
       }
-      if (F.trace && lane == 0 && s < 1024 && (blockIdx.x == 5 || blockIdx.x == gridDim.x / 2 + 5))
-        F.trace[8 * gridDim.x + (blockIdx.x == 5 ? 0 : 2048) + 2 * s] = wall_clock64(),
-        F.trace[8 * gridDim.x + (blockIdx.x == 5 ? 0 : 2048) + 2 * s + 1] = trPolls;
       if (s < nSteps && !dead)  // hands the step's rows to the publisher
         __hip_atomic_store(consumed, st[j & 1].end, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       prefetch(s + D, ex0[j], ex1[j]);
@@ -755,8 +752,8 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *f
   F.trace = nullptr;
   const char *tracePath = getenv("NG_SGS_TRACE");
   if (tracePath) {
-    NG_HIP(hipMalloc(&F.trace, sizeof(long long) * (8 * (size_t)fd.nChunks + 4096)));
-    NG_HIP(hipMemsetAsync(F.trace, 0, sizeof(long long) * (8 * (size_t)fd.nChunks + 4096), h->stream));
+    NG_HIP(hipMalloc(&F.trace, sizeof(long long) * 8 * (size_t)fd.nChunks));
+    NG_HIP(hipMemsetAsync(F.trace, 0, sizeof(long long) * 8 * (size_t)fd.nChunks, h->stream));
   }
   int *err = (int *)(h->dReduce + REDUCE_CAP) + 2;
   const dim3 block(64 * (2 + FLOW_LOADERS));
@@ -770,7 +767,7 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *f
     k_flow_sweep<FWD, 2, 16, 1><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
   NG_HIP(hipGetLastError());
   if (tracePath) {  // development aid: the last sweep's per-chunk clocks (100 MHz ticks), one file per direction
-    std::vector<long long> t((size_t)fd.nChunks * 8 + 4096);
+    std::vector<long long> t((size_t)fd.nChunks * 8);
     NG_HIP(hipStreamSynchronize(h->stream));
     NG_HIP(hipMemcpy(t.data(), F.trace, sizeof(long long) * t.size(), hipMemcpyDeviceToHost));
     (void)hipFree(F.trace);
@@ -780,10 +777,7 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *f
         fprintf(f, "%d %lld %lld %lld %lld %lld %lld %lld %lld\n", c, t[8 * c], t[8 * c + 1], t[8 * c + 2], t[8 * c + 3],
                 t[8 * c + 4], t[8 * c + 5], t[8 * c + 6], t[8 * c + 7]);
       fclose(f);
-      if (FILE *f2 = fopen((std::string(tracePath) + (FWD ? ".fwd" : ".bwd") + ".steps").c_str(), "w")) {
-        for (int i = 0; i < 4096; ++i) fprintf(f2, "%lld\n", t[8 * (size_t)fd.nChunks + i]);
-        fclose(f2);
-      }
+
     }
   }
   return NALU_GPU_OK;
