@@ -143,7 +143,7 @@ def build_rank(n, rank, nranks, device, strong=False):
     return R.S, R.F, R.g, R.comm
 
 
-def cpu_baseline(n_cpu, workload="continuity"):
+def cpu_baseline(n_cpu, workload="continuity", precond="jacobi"):
     """The oracle ("port" of the reference algorithm: AoS gathers, per-edge sumInto with
     sorted-row scan, CSR SpMV, Jacobi-CG / GMRES) timed on the host cores for ONE step of the
     benchmarked workload on an n_cpu^3 box (n_cpu = 256: the benchmarked box itself).
@@ -191,7 +191,8 @@ def cpu_baseline(n_cpu, workload="continuity"):
                 ls.reset_rows([0])
                 ls.sum_into([0], [0.0 - p[0]], [1.0])
             t1 = time.perf_counter()
-            out = ls.solve("gmres" if scalar else "cg", "jacobi", tolerance=1e-5, max_iterations=50, kspace=50)
+            out = ls.solve("gmres" if scalar else "cg", precond if scalar else "jacobi", tolerance=1e-5,
+                           max_iterations=50, kspace=50)
             t2 = time.perf_counter()
             r = (t1 - t0, t2 - t1, out["iters"])
             if best is None or r[0] + r[1] < best[0] + best[1]:
@@ -200,7 +201,7 @@ def cpu_baseline(n_cpu, workload="continuity"):
 
     a1, s1, it1 = one_step(True)
     am, sm, itm = one_step("omp", reps=2)  # best of two
-    what = "GMRES(50)/Jacobi" if scalar else "Jacobi-CG"
+    what = f"GMRES(50)/{precond}" if scalar else "Jacobi-CG"
     return dict(value=S.n_edges / (am + sm), unit="edges/s", cores=cores, kind="port",
                 sample=f"1 step ({workload} assembly + {itm} {what} its) on a {n_cpu}^3-node box, "
                        f"oracle/nalu_oracle.c -O3 -march=native -fopenmp, {cores} threads with per-thread "
@@ -245,6 +246,9 @@ def main():
                     help="iterations between host polls of the device convergence flag (0 = library default 10; "
                          "results do not depend on it)")
     ap.add_argument("--variants", action="store_true", help="also time the colored/atomic scatter variants")
+    ap.add_argument("--precond", default="jacobi", choices=["jacobi", "sgs", "mt_sgs", "chebyshev"],
+                    help="preconditioner of the scalar workload's GMRES(50) (the reference's edge regression inputs use "
+                         "sgs for transport, reg_tests/test_files/periodic3dEdge/periodic3dEdge.i:9-16)")
     ap.add_argument("--workload", default="continuity", choices=["continuity", "scalar"],
                     help="continuity = the headline Poisson step (default); scalar = BASELINE config 4: "
                          "scalar transport edge assembly (upwind, limiter) + mass term + GMRES(50)/Jacobi")
@@ -296,7 +300,7 @@ def main():
                                       max_iterations=50, kspace=50, check_every=a.check_every)
     eq = R.continuity_eqsys(cfg, a.mode)
     if a.workload == "scalar":
-        cfg = nalu_amd.LinearSolverConfig(method="gmres", preconditioner="jacobi", tolerance=1e-5,
+        cfg = nalu_amd.LinearSolverConfig(method="gmres", preconditioner=a.precond, tolerance=1e-5,
                                           max_iterations=50, kspace=50)
         eq = R.scalar_eqsys(cfg, device, a.mode)
 
@@ -415,7 +419,7 @@ def main():
         step_txt = ("continuity edge assembly + pinned node + Jacobi-CG (tol 1e-5, max_it 50)"
                     if a.workload == "continuity" else
                     "scalar transport edge assembly (upwind, van Leer limiter) + mass term + "
-                    "GMRES(50)/Jacobi (tol 1e-5, max_it 50)")
+                    f"GMRES(50)/{a.precond} (tol 1e-5, max_it 50)")
         if world == 1:
             wl = f"Hex8 box {n}^3 nodes on one GPU: "
         elif a.scaling == "strong":
@@ -470,7 +474,7 @@ def main():
         if strong:
             out["strong"] = strong
         if world == 1 and a.cpu_n > 0:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.workload)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.workload, a.precond)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
