@@ -211,7 +211,7 @@ struct FlowCfg {
   static constexpr int ROW_BYTES = 8 * W + 4 * W + 2 * W + 8 + 8 + 4 + 4 + 8;
   static size_t lds_bytes(int ring, int maxSteps)
   {
-    return 8u * (size_t)(ring + 2) + (size_t)NSR * ROW_BYTES + 4u * (size_t)(NG + 4 + maxSteps + 2);
+    return 8u * (size_t)(ring + 2 + 2 * NSR) + (size_t)NSR * ROW_BYTES + 4u * (size_t)(NG + 4 + maxSteps + 2);
   }
 };
 
@@ -257,12 +257,15 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
   if (done && *done) return;
   extern __shared__ double flowLds[];
   const int ring = F.ringMask + 1;
-  double *tring = flowLds;             // [ring] values of the chunk's last rows, [ring] = 0.0
-  double *sA = tring + ring + 2;       // [W][NSR] matrix values (0.0: padding)
+  double *tring = flowLds;             // [ring] values of the chunk's last rows, [ring] = 0.0, then [NSR][2]: the
+                                       // values of other chunks a staged row needs (put there by the consumer at
+                                       // the row's step, so that all W entries of a row are read the same way)
+  const int exBase = ring + 2;
+  double *sA = tring + exBase + 2 * NSR;  // [W][NSR] matrix values (0.0: padding)
   double *sR = sA + W * NSR;           // r_i (forward) / t_i (backward)
   double *sDV = sR + NSR;              // 1 / d_i
   unsigned long long *sT = (unsigned long long *)(sDV + NSR);  // [WQ][NSR] ring slots of four entries, 16 bits each
-  int2 *sG = (int2 *)(sT + WQ * NSR);  // rows of the first two entries of other chunks (negative: no such entry)
+  int2 *sG = (int2 *)(sT + WQ * NSR);  // rows of the first two entries of other chunks (none: a row of this chunk)
   int *sC = (int *)(sG + NSR);         // [W][NSR] entry codes (the rare row that has to poll reads them)
   int *sRow = sC + W * NSR;            // matrix row + FLOW_VISIBLE / FLOW_REARM
   int *sM = sRow + NSR;                // k0 | k1 << 8 | next << 16: entries of other chunks (first, second: 255 = none; count)
@@ -298,6 +301,7 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
           __hip_atomic_store(abortFlag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           return;
         }
+        __builtin_amdgcn_s_sleep(1);  // (leave the issue slots to the consumers that share the SIMD)
         continue;
       }
       spins = 0;
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
           sR[slot] = rr[b];
           sDV[slot] = dd[b];
           sRow[slot] = raw[b];
-          int g0 = dummyRow | (int)0x80000000, g1 = g0, ne = 0, k0 = 255, k1 = 255;
+          int g0 = dummyRow, g1 = dummyRow, ne = 0, k0 = 255, k1 = 255;
           unsigned long long packed[WQ];
 #pragma unroll
           for (int k = 0; k < W; ++k) {
@@ -386,10 +390,15 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
             if (c == FLOW_PAD) av[b][k] = 0.0;  // (the schedule's padding carries no value)
             sC[k * NSR + slot] = c;
             sA[k * NSR + slot] = av[b][k];
-            const unsigned ts = c > 0 ? (unsigned)((q - c) & F.ringMask) : (unsigned)ring;  // ring: the 0.0 slot
+            // ring slot of an in-chunk entry; the row's own two slots for the first two entries of other
+            // chunks; the slot that holds 0.0 for padding (and for further entries of other chunks: such a row
+            // is computed entry by entry)
+            const bool ext = c < 0 && c != FLOW_PAD;
+            const unsigned ts = c > 0 ? (unsigned)((q - c) & F.ringMask)
+                                : ext && ne < 2 ? (unsigned)(exBase + 2 * slot + ne) : (unsigned)ring;
             if (k % 4 == 0) packed[k / 4] = 0;
             packed[k / 4] |= (unsigned long long)ts << (16 * (k % 4));
-            if (c < 0 && c != FLOW_PAD) {
+            if (ext) {
               if (ne == 0) { g0 = ~c; k0 = k; }
               if (ne == 1) { g1 = ~c; k1 = k; }
               ++ne;
@@ -407,7 +416,8 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
     return;
   }
 
-  // ---- consumer
+  // ---- consumer: its instruction stream is the sweep's critical path, the other waves of the CU yield
+  __builtin_amdgcn_s_setprio(3);
   const int nSteps = C.nSteps;
   // first rows of steps vbase .. vbase + 63, one per lane (uniform reads without a memory access)
   int vbase = 0;
@@ -449,9 +459,9 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
     int2 g = make_int2(dummyRow, dummyRow);
     const int q = p0 + lane;
     if (!dead && q < p1) g = sG[q & (NSR - 1)];
-    e0 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + (g.x & 0x7fffffff)),
+    e0 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + g.x),
                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    e1 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + (g.y & 0x7fffffff)),
+    e1 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + g.y),
                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   };
   // a step's rows out of the staging ring: read one step ahead, off the chain of dependent values
@@ -485,17 +495,14 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
   };
   auto compute = [&](const Stage &S, double e0, double e1) {
     if (S.act) {
-      const int k0 = S.meta & 255, k1 = (S.meta >> 8) & 255;
+      *(double2 *)(tring + exBase + 2 * (S.q & (NSR - 1))) = make_double2(e0, e1);
       double tv[W];
 #pragma unroll
       for (int k = 0; k < W; ++k) tv[k] = tring[(S.t[k / 4] >> (16 * (k % 4))) & 0xffff];
       double acc = FWD ? S.own : 0.0;
 #pragma unroll
-      for (int k = 0; k < W; ++k) {
-        // (padding: 0.0 * 0.0, which changes neither a forward nor a backward partial sum)
-        const double v = k == k0 ? e0 : k == k1 ? e1 : tv[k];
-        acc = FWD ? acc - S.a[k] * v : acc + S.a[k] * v;
-      }
+      for (int k = 0; k < W; ++k)  // (padding: 0.0 * 0.0, which changes neither a forward nor a backward partial sum)
+        acc = FWD ? acc - S.a[k] * tv[k] : acc + S.a[k] * tv[k];
       if (__builtin_expect(late(S, e0, e1) || (S.meta >> 16) > 2, 0)) {
         // a value that is still not there (or a third entry of another chunk): the row again, entry by
         // entry, polling.  One copy of this loop per step: the unrolled round has to stay inside the
@@ -525,8 +532,9 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
     const int q = p0 + lane;
     if (!dead && q < p1) {
       const int2 g = sG[q & (NSR - 1)];
-      if (g.x >= 0) (void)flow_poll(flow + g.x, err);
-      if (g.y >= 0) (void)flow_poll(flow + g.y, err);
+      const int meta = sM[q & (NSR - 1)];
+      if ((meta & 255) != 255) (void)flow_poll(flow + g.x, err);
+      if (((meta >> 8) & 255) != 255) (void)flow_poll(flow + g.y, err);
     }
     refetch();
     if (F.trace) { trPollTicks += wall_clock64() - trT0; ++trPolls; }
@@ -821,6 +829,7 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
                   : fd.depth == 8 ? FlowA8::lds_bytes(ring, s.maxSteps)
                   : fd.depth == 4 ? FlowA4::lds_bytes(ring, s.maxSteps)
                                   : FlowA2::lds_bytes(ring, s.maxSteps);
+    if (getenv("NG_SGS_LDS_PAD")) fd.ldsBytes += (size_t)atoi(getenv("NG_SGS_LDS_PAD"));  // development aid: fewer workgroups per CU
     if (fd.ldsBytes > FLOW_MAX_LDS) return NALU_GPU_OK;
     fd.ring = ring;
     fd.wMax = s.wMax;
