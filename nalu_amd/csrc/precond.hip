@@ -523,21 +523,27 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
   };
   // A value asked for D steps ahead was not there yet: this chunk runs right behind a producer.  Going
   // on step by step would cost a memory round trip per step (and every chunk behind this one would
-  // inherit that pace).  Instead wait until the producers are D - 1 steps further, then ask again for
-  // the values of steps s .. s + D - 1: one wait per D steps.
-  auto recover = [&](int s, auto &&refetch) {
+  // inherit that pace).  Instead ask again for the values of steps s .. s + D - 1, all of them at once,
+  // until they are all there: one wait per D steps, and the loads that end it bring the values.
+  auto recover = [&](auto &&refetch_missing) {
     const long long trT0 = F.trace ? wall_clock64() : 0;
-    const int p0 = off(s + D - 1), p1 = off(s + D);
-    ensure(p1);
-    const int q = p0 + lane;
-    if (!dead && q < p1) {
-      const int2 g = sG[q & (NSR - 1)];
-      const int meta = sM[q & (NSR - 1)];
-      if ((meta & 255) != 255) (void)flow_poll(flow + g.x, err);
-      if (((meta >> 8) & 255) != 255) (void)flow_poll(flow + g.y, err);
+    int spins = 0;
+    while (__builtin_amdgcn_ballot_w64(refetch_missing()) != 0) {
+      ++spins;
+      if ((spins & 15) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      if (spins >= FLOW_MAX_POLL) break;  // (the rows' own polls report the failure)
+      if (spins >= 16) __builtin_amdgcn_s_sleep(32);
+      else if (spins >= 4) __builtin_amdgcn_s_sleep(8);
     }
-    refetch();
     if (F.trace) { trPollTicks += wall_clock64() - trT0; ++trPolls; }
+  };
+  // does step s need a value that is not in (e0, e1)?
+  auto missing = [&](int s, double e0, double e1) {
+    const int p0 = off(s), p1 = off(s + 1);
+    const int q = p0 + lane;
+    if (dead || q >= p1) return false;
+    const int meta = sM[q & (NSR - 1)];
+    return ((meta & 255) != 255 && is_sent(e0)) || (((meta >> 8) & 255) != 255 && is_sent(e1));
   };
   // a ring slot is written again `ring` rows later: the publisher must have stored the old row by then
   int pubSeen = 0;
@@ -575,9 +581,13 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
       if (!dead) {
         const Stage &S = st[j & 1];
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(late(S, ex0[j], ex1[j])) != 0, 0))
-          recover(s, [&]() {
+          recover([&]() {
 #pragma unroll
             for (int jj = 0; jj < D; ++jj) prefetch(s + jj, ex0[(j + jj) % D], ex1[(j + jj) % D]);
+            bool miss = false;
+#pragma unroll
+            for (int jj = 0; jj < D; ++jj) miss |= missing(s + jj, ex0[(j + jj) % D], ex1[(j + jj) % D]);
+            return miss;
           });
         compute(S, ex0[j], ex1[j]);
       }
