@@ -807,7 +807,7 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
   if (h->flowState != 0) return NALU_GPU_OK;
   const int n = h->nOwned;
   h->flowState = -1;
-  if (n == 0) return NALU_GPU_OK;
+  if (n == 0 || n > FLOW_ROW_MASK) return NALU_GPU_OK;  // (two flag bits ride on the row numbers)
   int chunkRows = getenv("NG_SGS_CHUNK") ? atoi(getenv("NG_SGS_CHUNK")) : 1024;
   chunkRows = std::min(std::max(chunkRows, 64), 2048);
   int By = 8, Bz = 8;

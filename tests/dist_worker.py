@@ -178,6 +178,20 @@ def gpu_test(rank, world, method, block=False):
         ref = ls.solve(method, "sgs", **kw)
         g.solve(nalu_amd.LinearSolverConfig(method=method, preconditioner="sgs", **kw))
         same_history(g, ref)
+    else:
+        # on a slab (owned rows + ghost columns) the sweeps are the rank's own: the dataflow schedule against
+        # the one with a launch per level, bit for bit
+        cfg_sgs = nalu_amd.LinearSolverConfig(method=method, preconditioner="sgs", **kw)
+        g.solve(cfg_sgs)
+        assert g.sgs_schedule()["mode"] == "flow"
+        it1, h1 = g.linearSolveIterations, np.array(g.history)
+        os.environ["NG_SGS_MODE"] = "levels"
+        try:
+            g.solve(cfg_sgs)
+            assert g.sgs_schedule()["mode"] == "levels"
+        finally:
+            os.environ.pop("NG_SGS_MODE")
+        assert g.linearSolveIterations == it1 and np.array_equal(h1, np.array(g.history))
     # Chebyshev applies the distributed operator (halo exchange inside every application), so
     # unlike SGS it is the same preconditioner on any rank count
     ref = ls.solve(method, "chebyshev", **kw)
