@@ -263,18 +263,20 @@ struct nalu_gpu_linsys {
   double *dLmR = nullptr, *dLmT = nullptr, *dLmZ = nullptr;
 
   // dataflow SGS sweeps (precond.hip, sgs_flow.hpp): one launch per sweep, chunks of rows wait
-  // for each other through dFlowT / dFlowZ (data-as-flag)
+  // for each other through the exchange buffers (data-as-flag: all-ones NaN = "not computed yet")
   int flowState = 0;  // 0 not built, 1 ready, -1 not available for this matrix (level launches instead)
   struct FlowDir {
     void *dChunks = nullptr;  // nalu_gpu::FlowChunk[nChunks], processing order
-    int *dRowOf = nullptr, *dCode = nullptr, *dSteps = nullptr;
+    int *dRowOf = nullptr, *dPubOf = nullptr, *dCode = nullptr, *dSteps = nullptr;
+    double *dXch = nullptr;  // exchange buffer: the rows other chunks read, in schedule order (nVisible)
+    int nVisible = 0;
     long long *dSrc = nullptr;  // SELL position of every entry's value (-1: pad)
     double *dVal = nullptr;
     int nChunks = 0, wMax = 0, ring = 0, depth = 0, maxSteps = 0;
     long long nEnt = 0;
     size_t ldsBytes = 0;
   } flow[2];  // forward, backward
-  double *dFlowT = nullptr, *dFlowZ = nullptr;  // nOwned each, all-ones NaN = "not computed yet"
+  double *dFlowT = nullptr;  // nOwned: t = (D + L)^-1 r between the two sweeps
   bool flowTiled = false;
   int flowTile[4] = {0, 0, 0, 0};  // Q, P, By, Bz of the lattice tiling
 

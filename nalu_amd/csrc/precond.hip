@@ -182,8 +182,6 @@ __global__ __launch_bounds__(256) void k_mc_sweep(SellView A, const int *__restr
 // grid drains and nalu_gpu_solve reports the failure.  Workgroups only wait for chunks earlier in
 // the dispatch order (flow_build checks it), which are running or finished.
 constexpr unsigned long long FLOW_SENT = ~0ull;
-constexpr int FLOW_REARM = 0x40000000;  // rowOf bit 30 (set in ensure_sgs_flow): visible in the OTHER sweep's schedule
-constexpr int FLOW_ROW_MASK = 0x3fffffff;
 constexpr int FLOW_LOADERS = 3;       // waves 2 to 4 (wave 0: consumer, wave 1: publisher)
 constexpr int FLOW_PUB_WINDOW = 256;  // rows the publisher may lag behind the consumer
 constexpr int FLOW_MAX_POLL = 1 << 20;      // ~0.6 s of polling one value
@@ -191,10 +189,11 @@ constexpr int FLOW_MAX_LDS_SPIN = 1 << 24;  // loaders <-> consumer inside one w
 
 struct FlowView {
   const FlowChunk *chunks;
-  const int *rowOf, *code, *steps;
+  const int *rowOf, *pubOf, *code, *steps;
   const double *val;
   int ringMask;  // LDS ring of in-chunk values: ring - 1, ring >= largest lookback + 64
   int maxSteps;  // most steps of any chunk (the step offsets of a chunk are copied to LDS)
+  int nVisible;  // slots of the exchange buffer
   long long *trace;  // development aid (NG_SGS_TRACE): per chunk, clock at start / after the first step / at the end
 };
 
@@ -207,8 +206,8 @@ struct FlowCfg {
   static constexpr int GROUP = GB * 64;
   static constexpr int NSR = flow_pow2(D * 64 + GROUP + 64);
   static constexpr int NG = NSR / GROUP;
-  // per staged row: W values, W codes, W/4 packed ring slots, r, 1/d, row, meta, two rows of other chunks
-  static constexpr int ROW_BYTES = 8 * W + 4 * W + 2 * W + 8 + 8 + 4 + 4 + 8;
+  // per staged row: W values, W codes, W/4 packed ring slots, r, 1/d, row, exchange slot, meta, two slots of other chunks
+  static constexpr int ROW_BYTES = 8 * W + 4 * W + 2 * W + 8 + 8 + 4 + 4 + 4 + 8;
   static size_t lds_bytes(int ring, int maxSteps)
   {
     return 8u * (size_t)(ring + 2 + 2 * NSR) + (size_t)NSR * ROW_BYTES + 4u * (size_t)(NG + 4 + maxSteps + 2);
@@ -236,9 +235,10 @@ __device__ __forceinline__ double flow_poll(const double *p, int *err)
   return __longlong_as_double((long long)bits);
 }
 
-// FWD: flow_i = (in_i - sum_{c<i} a_ic flow_c) dinv_i              (in = r, flow = t)
-// else: flow_i = in_i - (sum_{i<c<n} a_ic flow_c) dinv_i, zout_i = flow_i   (in = t, flow = z)
-// rearm: the vector the NEXT sweep polls; the loaders reset this chunk's rows of it to "not computed"
+// FWD: out_i = (in_i - sum_{c<i} a_ic out_c) dinv_i              (in = r, out = t)
+// else: out_i = in_i - (sum_{i<c<n} a_ic out_c) dinv_i           (in = t, out = z)
+// xch: the exchange buffer of this sweep, all-ones NaNs at launch: the rows other chunks read are also
+// stored there (agent scope), in their slot of the schedule's numbering
 //
 // The consumer's step is the unit of the sweep's critical path (~3 n steps on an n^3 lattice, plus
 // the hops between chunks), so everything that can be is done by the other waves: the loaders turn
@@ -248,8 +248,8 @@ __device__ __forceinline__ double flow_poll(const double *p, int *err)
 template <bool FWD, int D, int W, int GB>
 __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView F, const int *__restrict__ done,
                                                                         const double *in,
-                                                                        const double *__restrict__ dinv, double *flow,
-                                                                        double *zout, double *rearm, int *err)
+                                                                        const double *__restrict__ dinv, double *xch,
+                                                                        double *out, int *err)
 {
   using Cfg = FlowCfg<D, W, GB>;
   constexpr int NSR = Cfg::NSR, NG = Cfg::NG, GROUP = Cfg::GROUP, WQ = W / 4;
@@ -267,8 +267,9 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
   unsigned long long *sT = (unsigned long long *)(sDV + NSR);  // [WQ][NSR] ring slots of four entries, 16 bits each
   int2 *sG = (int2 *)(sT + WQ * NSR);  // rows of the first two entries of other chunks (none: a row of this chunk)
   int *sC = (int *)(sG + NSR);         // [W][NSR] entry codes (the rare row that has to poll reads them)
-  int *sRow = sC + W * NSR;            // matrix row + FLOW_VISIBLE / FLOW_REARM
-  int *sM = sRow + NSR;                // k0 | k1 << 8 | next << 16: entries of other chunks (first, second: 255 = none; count)
+  int *sRow = sC + W * NSR;            // matrix row
+  int *sPub = sRow + NSR;              // its slot in the exchange buffer (-1: no other chunk reads it)
+  int *sM = sPub + NSR;                // k0 | k1 << 8 | next << 16: entries of other chunks (first, second: 255 = none; count)
   int *ready = sM + NSR;               // [NG]: group g staged <=> ready[g % NG] == g + 1
   int *consumed = ready + NG;          // rows the consumer has computed (their values are in tring)
   int *abortFlag = consumed + 1;
@@ -284,9 +285,9 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int m = C.m, w = C.w;
 
-  // rows without an entry of another chunk ask for this row's value instead (any valid address; one
-  // per chunk, or every workgroup would hit the same memory channel twice per step)
-  const int dummyRow = F.rowOf[C.rowOff] & FLOW_ROW_MASK;
+  // rows without an entry of another chunk ask for this slot instead (any valid address; one per
+  // chunk, or every workgroup would hit the same memory channel twice per step)
+  const int dummyRow = F.nVisible ? (int)(blockIdx.x % (unsigned)F.nVisible) : 0;
 
   if (wave == 1) {  // ---- publisher: the computed values out of the LDS ring to memory
     // (the consumer itself issues no store: vector-memory operations retire in order, and a wait for
@@ -309,13 +310,12 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
         const int q = q0 + lane;
         if (q < have) {
           const double v = tring[q & F.ringMask];
-          const int raw = sRow[q & (NSR - 1)], row = raw & FLOW_ROW_MASK;
-          // rows that other chunks read are published at once; the rest is only needed after the sweep
-          if (raw < 0)
-            __hip_atomic_store((unsigned long long *)(flow + row), (unsigned long long)__double_as_longlong(v),
+          const int pub = sPub[q & (NSR - 1)];
+          out[sRow[q & (NSR - 1)]] = v;  // (only needed after the sweep)
+          // rows that other chunks read are published at once
+          if (pub >= 0)
+            __hip_atomic_store((unsigned long long *)(xch + pub), (unsigned long long)__double_as_longlong(v),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else if (FWD) flow[row] = v;
-          if (!FWD) zout[row] = v;
         }
       }
       pub = have;
@@ -336,14 +336,14 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
       rawNext[b] = q < m ? F.rowOf[(size_t)C.rowOff + q] : 0;
     }
     for (int g = wave - 2; g < nGroups; g += FLOW_LOADERS) {
-      int row[GB], raw[GB], cd[GB][W];
+      int row[GB], pub[GB], cd[GB][W];
       double av[GB][W], rr[GB], dd[GB];
 #pragma unroll
       for (int b = 0; b < GB; ++b) {
         const int q = g * GROUP + b * 64 + lane;
         const bool ok = q < m;
-        raw[b] = rawNext[b];
-        row[b] = ok ? (raw[b] & FLOW_ROW_MASK) : -1;
+        row[b] = ok ? rawNext[b] : -1;
+        pub[b] = ok ? F.pubOf[(size_t)C.rowOff + q] : -1;
 #pragma unroll
         for (int k = 0; k < W; ++k) {
           cd[b][k] = FLOW_PAD;
@@ -381,7 +381,8 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
           const int slot = q & (NSR - 1);
           sR[slot] = rr[b];
           sDV[slot] = dd[b];
-          sRow[slot] = raw[b];
+          sRow[slot] = row[b];
+          sPub[slot] = pub[b];
           int g0 = dummyRow, g1 = dummyRow, ne = 0, k0 = 255, k1 = 255;
           unsigned long long packed[WQ];
 #pragma unroll
@@ -408,8 +409,6 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
           for (int j = 0; j < WQ; ++j) sT[j * NSR + slot] = packed[j];
           sG[slot] = make_int2(g0, g1);
           sM[slot] = k0 | (k1 << 8) | (ne << 16);
-          // (only the rows that the other sweep publishes to other chunks are ever polled)
-          if (raw[b] & FLOW_REARM) ((unsigned long long *)rearm)[row[b]] = FLOW_SENT;
         }
       __hip_atomic_store(&ready[g % NG], g + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -459,9 +458,9 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
     int2 g = make_int2(dummyRow, dummyRow);
     const int q = p0 + lane;
     if (!dead && q < p1) g = sG[q & (NSR - 1)];
-    e0 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + g.x),
+    e0 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(xch + g.x),
                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    e1 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(flow + g.y),
+    e1 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(xch + g.y),
                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   };
   // a step's rows out of the staging ring: read one step ahead, off the chain of dependent values
@@ -513,7 +512,7 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
         for (int k = 0; k < w; ++k) {
           const int c = sC[k * NSR + slot];
           if (c == FLOW_PAD) break;
-          const double v = c > 0 ? tring[(S.q - c) & F.ringMask] : flow_poll(flow + ~c, err);
+          const double v = c > 0 ? tring[(S.q - c) & F.ringMask] : flow_poll(xch + ~c, err);
           const double a = sA[k * NSR + slot];
           acc = FWD ? acc - a * v : acc + a * v;
         }
@@ -756,7 +755,7 @@ int flow_upload(const std::vector<T> &v, T **dst)
 }
 
 template <bool FWD>
-int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *flow, double *zout, double *rearm)
+int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *out)
 {
   const nalu_gpu_linsys::FlowDir &fd = h->flow[FWD ? 0 : 1];
   FlowView F;
@@ -767,6 +766,10 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *f
   F.val = fd.dVal;
   F.ringMask = fd.ring - 1;
   F.maxSteps = fd.maxSteps;
+  F.pubOf = fd.dPubOf;
+  F.nVisible = fd.nVisible;
+  // the exchange buffer starts as "nothing computed yet"
+  NG_HIP(hipMemsetAsync(fd.dXch, 0xFF, sizeof(double) * (size_t)std::max(fd.nVisible, 1), h->stream));
   F.trace = nullptr;
   const char *tracePath = getenv("NG_SGS_TRACE");
   if (tracePath) {
@@ -776,13 +779,13 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *f
   int *err = (int *)(h->dReduce + REDUCE_CAP) + 2;
   const dim3 block(64 * (2 + FLOW_LOADERS));
   if (fd.depth == 8)
-    k_flow_sweep<FWD, 8, 4, 4><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
+    k_flow_sweep<FWD, 8, 4, 4><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
   else if (fd.depth == 4)
-    k_flow_sweep<FWD, 4, 4, 2><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
+    k_flow_sweep<FWD, 4, 4, 2><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
   else if (fd.wMax <= 4)
-    k_flow_sweep<FWD, 2, 4, 2><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
+    k_flow_sweep<FWD, 2, 4, 2><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
   else
-    k_flow_sweep<FWD, 2, 16, 1><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, flow, zout, rearm, err);
+    k_flow_sweep<FWD, 2, 16, 1><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
   NG_HIP(hipGetLastError());
   if (tracePath) {  // development aid: the last sweep's per-chunk clocks (100 MHz ticks), one file per direction
     std::vector<long long> t((size_t)fd.nChunks * 8);
@@ -807,7 +810,7 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
   if (h->flowState != 0) return NALU_GPU_OK;
   const int n = h->nOwned;
   h->flowState = -1;
-  if (n == 0 || n > FLOW_ROW_MASK) return NALU_GPU_OK;  // (two flag bits ride on the row numbers)
+  if (n == 0) return NALU_GPU_OK;
   int chunkRows = getenv("NG_SGS_CHUNK") ? atoi(getenv("NG_SGS_CHUNK")) : 1024;
   chunkRows = std::min(std::max(chunkRows, 64), 2048);
   int By = 8, Bz = 8;
@@ -847,24 +850,13 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     fd.nChunks = (int)s.chunks.size();
     fd.nEnt = (long long)s.code.size();
   }
-  {  // a sweep resets, for the next sweep, the rows that sweep polls: the visible rows of the other schedule
-    std::vector<char> vis[2];
-    for (int dir = 0; dir < 2; ++dir) {
-      vis[dir].assign((size_t)n, 0);
-      for (int r : S[dir].rowOf)
-        if ((unsigned)r & FLOW_VISIBLE) vis[dir][(size_t)(r & FLOW_ROW_MASK)] = 1;
-    }
-    for (int dir = 0; dir < 2; ++dir)
-      for (int &r : S[dir].rowOf)
-        if (vis[1 - dir][(size_t)(r & FLOW_ROW_MASK)]) r |= FLOW_REARM;
-  }
   for (int dir = 0; dir < 2; ++dir) {
     nalu_gpu_linsys::FlowDir &fd = h->flow[dir];
     FlowSchedule &s = S[dir];
     // CSR entry -> position of its value in the SELL matrix
     for (const FlowChunk &C : s.chunks)
       for (int q = 0; q < C.m; ++q) {
-        const int i = s.rowOf[(size_t)C.rowOff + q] & FLOW_ROW_MASK;
+        const int i = s.rowOf[(size_t)C.rowOff + q];
         const long long so = h->hSliceOff[i / SELL_C] + i % SELL_C;
         for (int k = 0; k < C.w; ++k) {
           long long &e = s.src[(size_t)(C.entOff + (long long)k * C.m + q)];
@@ -875,6 +867,9 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     NG_TRY(flow_upload(s.chunks, &dc));
     fd.dChunks = dc;
     NG_TRY(flow_upload(s.rowOf, &fd.dRowOf));
+    NG_TRY(flow_upload(s.pubOf, &fd.dPubOf));
+    fd.nVisible = s.nVisible;
+    NG_HIP(hipMalloc(&fd.dXch, sizeof(double) * (size_t)std::max(s.nVisible, 1)));
     NG_TRY(flow_upload(s.code, &fd.dCode));
     NG_TRY(flow_upload(s.steps, &fd.dSteps));
     NG_TRY(flow_upload(s.src, &fd.dSrc));
@@ -882,7 +877,6 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     s = FlowSchedule();
   }
   NG_HIP(hipMalloc(&h->dFlowT, sizeof(double) * (size_t)n));
-  NG_HIP(hipMalloc(&h->dFlowZ, sizeof(double) * (size_t)n));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
@@ -916,12 +910,10 @@ int nalu_gpu::sgs_compute(nalu_gpu_linsys *h)
   NG_TRY(sgs_prepare(h));
   const int n = h->nOwned;
   if (n == 0) return NALU_GPU_OK;
-  if (flow_active(h)) {  // the values in schedule order; both result vectors "not computed yet"
+  if (flow_active(h)) {  // the values in schedule order
     for (auto &fd : h->flow)
       k_lm_gather_vals<<<(unsigned)((fd.nEnt + 255) / 256), 256, 0, h->stream>>>(fd.nEnt, fd.dSrc, h->dVals, fd.dVal);
     NG_HIP(hipGetLastError());
-    NG_HIP(hipMemsetAsync(h->dFlowT, 0xFF, sizeof(double) * (size_t)n, h->stream));
-    NG_HIP(hipMemsetAsync(h->dFlowZ, 0xFF, sizeof(double) * (size_t)n, h->stream));
     return NALU_GPU_OK;
   }
   k_lm_gather_vals<<<(unsigned)((h->lmFwdN + 255) / 256), 256, 0, h->stream>>>(h->lmFwdN, h->dLmFwdSrc, h->dVals,
@@ -943,10 +935,9 @@ int nalu_gpu::apply_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool use
   if (flow_active(h)) {
     if (h->nOwned == 0) return NALU_GPU_OK;
     const int *done = useDone ? &h->dScal->done : nullptr;
-    // t = (D + L)^-1 r into dFlowT (polled), then z = t - D^-1 U z into dFlowZ (polled) and z; each
-    // sweep resets the vector the next one polls (sgs_compute did it for the first)
-    NG_TRY(flow_launch<true>(h, done, r, h->dFlowT, nullptr, h->dFlowZ));
-    NG_TRY(flow_launch<false>(h, done, h->dFlowT, h->dFlowZ, z, h->dFlowT));
+    // t = (D + L)^-1 r into dFlowT, then z = t - D^-1 U z (each launch clears its exchange buffer first)
+    NG_TRY(flow_launch<true>(h, done, r, h->dFlowT));
+    NG_TRY(flow_launch<false>(h, done, h->dFlowT, z));
     return NALU_GPU_OK;
   }
   const int nf = (int)h->sgsFwdOff.size() - 1, nb = (int)h->sgsBwdOff.size() - 1;

@@ -12,7 +12,12 @@
 //     the steps, in-chunk values travel through an LDS ring, values of other chunks are polled;
 //   * per compact row p: rowOf[p] (the matrix row) and w entries in ascending column order (the
 //     order of the sequential sweep's sum): code > 0 = the value is p - code rows back in this
-//     chunk, code < 0 = ~code is the row of another chunk, FLOW_PAD = no entry.
+//     chunk, code < 0 = the value of a row of another chunk, FLOW_PAD = no entry;
+//   * the rows other chunks read ("visible") are numbered in schedule order: pubOf[p] is the slot of
+//     compact row p in the exchange buffer the chunks publish to and poll (-1: not visible), and
+//     ~code of an entry of another chunk is that row's slot.  The rows a step publishes, and the
+//     rows a step of a neighbouring tile needs, are then a few consecutive slots: a handful of
+//     memory requests per step instead of one per row.
 // Plain C++ (no HIP): scripts/flowcheck.cpp replays the schedule on the CPU against the
 // sequential sweep.
 #pragma once
@@ -26,7 +31,6 @@ namespace nalu_gpu {
 
 constexpr int FLOW_PAD = INT_MIN;
 constexpr int FLOW_STEP = 64;  // rows per step: one wavefront
-constexpr unsigned FLOW_VISIBLE = 0x80000000u;
 
 struct FlowChunk {   // 32 bytes, read by the device
   long long entOff;  // entry k of compact row q of the chunk: entOff + k * m + q
@@ -40,8 +44,9 @@ struct FlowChunk {   // 32 bytes, read by the device
 
 struct FlowSchedule {
   std::vector<FlowChunk> chunks;  // in processing (= dispatch) order
-  std::vector<int> rowOf;         // n: matrix row of every compact row; bit 31 (FLOW_VISIBLE): the row is read by
-                                  // other chunks, its value has to be published as it is computed
+  std::vector<int> rowOf;         // n: matrix row of every compact row
+  std::vector<int> pubOf;         // n: slot of the row in the exchange buffer, -1 if no other chunk reads it
+  int nVisible = 0;               // slots
   std::vector<int> code;          // entries
   std::vector<long long> src;     // entries: CSR entry index the value comes from (-1: pad)
   std::vector<int> steps;
@@ -146,8 +151,13 @@ inline std::string flow_build(int n, const int64_t *rowPtr, const int *colIdx, c
     S.chunks.push_back(C);
   }
   if (S.code.empty()) { S.code.push_back(FLOW_PAD); S.src.push_back(-1); }
-  for (int &r : S.rowOf)
-    if (visible[r]) r = (int)((unsigned)r | FLOW_VISIBLE);
+  // exchange slots in schedule order, then the entries of other chunks point at them
+  std::vector<int> slotOfRow((size_t)n, -1);
+  S.pubOf.assign((size_t)n, -1);
+  for (int p = 0; p < n; ++p)
+    if (visible[S.rowOf[p]]) slotOfRow[S.rowOf[p]] = S.pubOf[p] = S.nVisible++;
+  for (int &c : S.code)
+    if (c < 0 && c != FLOW_PAD) c = ~slotOfRow[~c];
   return std::string();
 }
 

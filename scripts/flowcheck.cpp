@@ -108,7 +108,7 @@ static int check(const char *name, const Csr &A, int chunkRows, int By, int Bz)
         if (s1 - s0 > FLOW_STEP || s1 <= s0) { printf("%s: bad step %d..%d\n", name, s0, s1); return 1; }
         std::vector<double> out((size_t)(s1 - s0));
         for (int q = s0; q < s1; ++q) {
-          const int row = S.rowOf[(size_t)C.rowOff + q] & 0x7fffffff;
+          const int row = S.rowOf[(size_t)C.rowOff + q];
           double acc = fwd ? in[row] : 0.0;
           for (int k = 0; k < C.w; ++k) {
             const size_t idx = (size_t)(C.entOff + (long long)k * C.m + q);
@@ -119,6 +119,7 @@ static int check(const char *name, const Csr &A, int chunkRows, int By, int Bz)
               if (code > S.maxLookback || q - code < 0) { printf("%s: bad lookback\n", name); return 1; }
               v = ringBuf[(size_t)((q - code) & (ring - 1))];
             } else {
+              if (~code < 0 || ~code >= S.nVisible) { printf("%s: bad exchange slot\n", name); return 1; }
               v = flow[(size_t)~code];
               if (std::isnan(v)) ++notReady;
             }
@@ -130,10 +131,9 @@ static int check(const char *name, const Csr &A, int chunkRows, int By, int Bz)
         }
         for (int q = s0; q < s1; ++q) {  // a step's rows are independent: written after all were read
           ringBuf[(size_t)(q & (ring - 1))] = out[(size_t)(q - s0)];
-          // only the rows marked visible reach other chunks
-          if ((unsigned)S.rowOf[(size_t)C.rowOff + q] & FLOW_VISIBLE)
-            flow[(size_t)(S.rowOf[(size_t)C.rowOff + q] & 0x7fffffff)] = out[(size_t)(q - s0)];
-          all[(size_t)(S.rowOf[(size_t)C.rowOff + q] & 0x7fffffff)] = out[(size_t)(q - s0)];
+          // only the visible rows reach other chunks, through their slots of the exchange buffer
+          if (S.pubOf[(size_t)C.rowOff + q] >= 0) flow[(size_t)S.pubOf[(size_t)C.rowOff + q]] = out[(size_t)(q - s0)];
+          all[(size_t)S.rowOf[(size_t)C.rowOff + q]] = out[(size_t)(q - s0)];
         }
       }
     }
