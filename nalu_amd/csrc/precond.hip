@@ -206,8 +206,8 @@ struct FlowCfg {
   static constexpr int GROUP = GB * 64;
   static constexpr int NSR = flow_pow2(D * 64 + GROUP + 64);
   static constexpr int NG = NSR / GROUP;
-  // per staged row: W values, W codes, W/4 packed ring slots, r, 1/d, row, exchange slot, meta, two slots of other chunks
-  static constexpr int ROW_BYTES = 8 * W + 4 * W + 2 * W + 8 + 8 + 4 + 4 + 4 + 8;
+  // per staged row: W values, W/4 packed ring slots, r, 1/d, row, exchange slot, meta, two slots of other chunks
+  static constexpr int ROW_BYTES = 8 * W + 2 * W + 8 + 8 + 4 + 4 + 4 + 8;
   static size_t lds_bytes(int ring, int maxSteps)
   {
     return 8u * (size_t)(ring + 2 + 2 * NSR) + (size_t)NSR * ROW_BYTES + 4u * (size_t)(NG + 4 + maxSteps + 2);
@@ -265,9 +265,8 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
   double *sR = sA + W * NSR;           // r_i (forward) / t_i (backward)
   double *sDV = sR + NSR;              // 1 / d_i
   unsigned long long *sT = (unsigned long long *)(sDV + NSR);  // [WQ][NSR] ring slots of four entries, 16 bits each
-  int2 *sG = (int2 *)(sT + WQ * NSR);  // rows of the first two entries of other chunks (none: a row of this chunk)
-  int *sC = (int *)(sG + NSR);         // [W][NSR] entry codes (the rare row that has to poll reads them)
-  int *sRow = sC + W * NSR;            // matrix row
+  int2 *sG = (int2 *)(sT + WQ * NSR);  // exchange slots of the first two entries of other chunks (-1: none)
+  int *sRow = (int *)(sG + NSR);       // matrix row
   int *sPub = sRow + NSR;              // its slot in the exchange buffer (-1: no other chunk reads it)
   int *sM = sPub + NSR;                // k0 | k1 << 8 | next << 16: entries of other chunks (first, second: 255 = none; count)
   int *ready = sM + NSR;               // [NG]: group g staged <=> ready[g % NG] == g + 1
@@ -383,13 +382,12 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
           sDV[slot] = dd[b];
           sRow[slot] = row[b];
           sPub[slot] = pub[b];
-          int g0 = dummyRow, g1 = dummyRow, ne = 0, k0 = 255, k1 = 255;
+          int g0 = -1, g1 = -1, ne = 0, k0 = 255, k1 = 255;
           unsigned long long packed[WQ];
 #pragma unroll
           for (int k = 0; k < W; ++k) {
             const int c = cd[b][k];
             if (c == FLOW_PAD) av[b][k] = 0.0;  // (the schedule's padding carries no value)
-            sC[k * NSR + slot] = c;
             sA[k * NSR + slot] = av[b][k];
             // ring slot of an in-chunk entry; the row's own two slots for the first two entries of other
             // chunks; the slot that holds 0.0 for padding (and for further entries of other chunks: such a row
@@ -455,9 +453,16 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
   auto prefetch = [&](int s, double &e0, double &e1) {
     const int p0 = off(s), p1 = off(s + 1);
     ensure(p1);
-    int2 g = make_int2(dummyRow, dummyRow);
+    int2 g = make_int2(-1, -1);
     const int q = p0 + lane;
     if (!dead && q < p1) g = sG[q & (NSR - 1)];
+    // lanes with nothing to ask for ride on the step's first row's request (the first row of a step of an
+    // interior tile has both entries): no memory request of their own
+    int f0 = __builtin_amdgcn_readfirstlane(g.x), f1 = __builtin_amdgcn_readfirstlane(g.y);
+    f0 = f0 < 0 ? dummyRow : f0;
+    f1 = f1 < 0 ? dummyRow : f1;
+    g.x = g.x < 0 ? f0 : g.x;
+    g.y = g.y < 0 ? f1 : g.y;
     e0 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(xch + g.x),
                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     e1 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(xch + g.y),
@@ -506,11 +511,13 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
         // a value that is still not there (or a third entry of another chunk): the row again, entry by
         // entry, polling.  One copy of this loop per step: the unrolled round has to stay inside the
         // instruction cache.
+        // (Its codes come from memory: LDS only holds what the usual path needs, so that three
+        // workgroups fit a CU.)
         const int slot = S.q & (NSR - 1);
         acc = FWD ? S.own : 0.0;
 #pragma nounroll
         for (int k = 0; k < w; ++k) {
-          const int c = sC[k * NSR + slot];
+          const int c = F.code[(size_t)(C.entOff + (long long)k * m + S.q)];
           if (c == FLOW_PAD) break;
           const double v = c > 0 ? tring[(S.q - c) & F.ringMask] : flow_poll(xch + ~c, err);
           const double a = sA[k * NSR + slot];
