@@ -171,13 +171,14 @@ __global__ __launch_bounds__(256) void k_mc_sweep(SellView A, const int *__restr
 // One launch per sweep, one workgroup per chunk of rows, dispatched in the schedule's order.  Wave 0
 // (the consumer) walks the chunk's steps: at most 64 independent rows each, same operations in
 // the same order per row as the sequential sweep, so the result is bit-identical to it.  Values of
-// the chunk's own earlier rows come from an LDS ring; values of other chunks are read from the
-// result vector itself, which starts as all-ones NaNs ("not computed yet", data-as-flag: an
-// 8-byte agent-scope store publishes a value, ~0.6 us from store to a polling load on MI355X,
-// scripts/flowbench.hip) -- the consumer asks for them D steps ahead and only spins when one is
-// still missing at its step.  Wave 1 (the publisher) stores the computed values from the LDS ring
-// to memory; waves 2-4 (the loaders) stream the chunk's rows, D + 2 steps or more ahead, into an
-// LDS staging ring: matrix values, entry codes, r, 1/d, row numbers.
+// the chunk's own earlier rows come from an LDS ring; values of other chunks are read from an
+// exchange buffer (the rows other chunks read, in schedule order), which starts as all-ones NaNs
+// ("not computed yet", data-as-flag: an 8-byte agent-scope store publishes a value, ~0.6 us from
+// store to a polling load on MI355X, scripts/flowbench.hip) -- the consumer asks for them D steps
+// ahead and only waits when one is still missing at its step.  Wave 1 (the publisher) stores the
+// computed values from the LDS ring to memory; waves 2-4 (the loaders) stream the chunk's rows,
+// D + 2 steps or more ahead, into an LDS staging ring: matrix values, ring slots of the entries, r,
+// 1/d, row numbers, exchange slots.
 // Every spin is bounded; a wave that gives up sets *err, after which no wave waits any more, the
 // grid drains and nalu_gpu_solve reports the failure.  Workgroups only wait for chunks earlier in
 // the dispatch order (flow_build checks it), which are running or finished.
