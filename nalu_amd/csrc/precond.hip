@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -825,13 +826,22 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
   if (const char *t = getenv("NG_SGS_TILE")) {
     if (sscanf(t, "%d,%d", &By, &Bz) != 2) By = Bz = 0;  // anything else: contiguous chunks only
   }
+  int hostThreads = getenv("NG_HOST_THREADS") ? atoi(getenv("NG_HOST_THREADS")) : (int)std::thread::hardware_concurrency();
+  hostThreads = std::min(std::max(hostThreads, 2), 16);
   std::vector<int> chunkOf;
   FlowTiling T = flow_chunking(n, h->rowPtr.data(), h->colIdx.data(), chunkRows, By, Bz, chunkOf);
   FlowSchedule S[2];
   for (int attempt = 0; attempt < 2; ++attempt) {
-    bool ok = true;
-    for (int dir = 0; dir < 2 && ok; ++dir)
-      ok = flow_build(n, h->rowPtr.data(), h->colIdx.data(), chunkOf, T.nChunks, dir == 0, S[dir]).empty();
+    // both sweeps at once, each on half of the host threads (16 at most: a GPU's share of the node's cores)
+    std::string why[2];
+    {
+      std::thread other([&]() {
+        why[1] = flow_build(n, h->rowPtr.data(), h->colIdx.data(), chunkOf, T.nChunks, false, S[1], hostThreads / 2);
+      });
+      why[0] = flow_build(n, h->rowPtr.data(), h->colIdx.data(), chunkOf, T.nChunks, true, S[0], hostThreads / 2);
+      other.join();
+    }
+    bool ok = why[0].empty() && why[1].empty();
     for (int dir = 0; dir < 2 && ok; ++dir) ok = S[dir].maxLookback + FLOW_STEP <= 4096;
     if (ok) break;
     if (!T.tiled) return NALU_GPU_OK;  // contiguous chunks are always a valid order: only the ring can fail
@@ -862,7 +872,8 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     nalu_gpu_linsys::FlowDir &fd = h->flow[dir];
     FlowSchedule &s = S[dir];
     // CSR entry -> position of its value in the SELL matrix
-    for (const FlowChunk &C : s.chunks)
+    flow_parallel_for((int)s.chunks.size(), hostThreads, [&](int ic) {
+      const FlowChunk &C = s.chunks[(size_t)ic];
       for (int q = 0; q < C.m; ++q) {
         const int i = s.rowOf[(size_t)C.rowOff + q];
         const long long so = h->hSliceOff[i / SELL_C] + i % SELL_C;
@@ -871,6 +882,7 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
           if (e >= 0) e = so + (e - h->rowPtr[i]) * SELL_C;
         }
       }
+    });
     FlowChunk *dc = nullptr;
     NG_TRY(flow_upload(s.chunks, &dc));
     fd.dChunks = dc;

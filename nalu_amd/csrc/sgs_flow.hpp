@@ -22,9 +22,11 @@
 // sequential sweep.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace nalu_gpu {
@@ -56,11 +58,32 @@ struct FlowSchedule {
   long long nExternal = 0;
 };
 
+// runs f(0) .. f(count - 1) on up to `threads` host threads (dynamic distribution)
+template <class F>
+inline void flow_parallel_for(int count, int threads, F f)
+{
+  threads = std::max(1, std::min(threads, count));
+  if (threads == 1) {
+    for (int i = 0; i < count; ++i) f(i);
+    return;
+  }
+  std::atomic<int> next(0);
+  auto work = [&]() {
+    for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) f(i);
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+  work();
+  for (std::thread &t : pool) t.join();
+}
+
 // chunkOf[i] = position of row i's chunk in the FORWARD processing order (0 .. nChunks-1); the
 // backward sweep processes the same chunks in reverse.  Returns an empty string, or the reason
-// this chunking cannot be used (a dependency on a later chunk).
+// this chunking cannot be used (a dependency on a later chunk).  The chunks are independent of
+// each other until the exchange slots are numbered: two parallel passes over the chunks (levels
+// and order; entries) around a prefix sum of their sizes.
 inline std::string flow_build(int n, const int64_t *rowPtr, const int *colIdx, const std::vector<int> &chunkOf,
-                              int nChunks, bool fwd, FlowSchedule &S)
+                              int nChunks, bool fwd, FlowSchedule &S, int threads = 1)
 {
   S = FlowSchedule();
   // rows of every chunk, ascending
@@ -74,17 +97,29 @@ inline std::string flow_build(int n, const int64_t *rowPtr, const int *colIdx, c
   }
   auto is_dep = [&](int i, int c) { return fwd ? c < i : (c > i && c < n); };
   std::vector<int> lvl((size_t)n, 0), pos((size_t)n, 0);
-  std::vector<char> visible((size_t)n, 0);
   S.rowOf.resize((size_t)n);
-  S.chunks.reserve((size_t)nChunks);
-  long long entTotal = 0;
-  int rowOff = 0;
-  std::vector<int> lcount, sorted;
-  for (int oc = 0; oc < nChunks; ++oc) {
+  // the non-empty chunks in processing order, and where their rows start
+  std::vector<int> order;
+  std::vector<FlowChunk> &chunks = S.chunks;
+  for (int oc = 0, rowOff = 0; oc < nChunks; ++oc) {
     const int c = fwd ? oc : nChunks - 1 - oc;
-    const int b = cnt[c], e = cnt[c + 1], m = e - b;
+    const int m = cnt[c + 1] - cnt[c];
     if (m == 0) continue;
-    // local levels: only the dependencies inside the chunk count
+    FlowChunk C{};
+    C.rowOff = rowOff;
+    C.m = m;
+    rowOff += m;
+    order.push_back(c);
+    chunks.push_back(C);
+  }
+  const int nc = (int)chunks.size();
+  std::vector<std::vector<int>> stepsOf((size_t)nc);
+  std::vector<int> badRow((size_t)nc, -1), badCol((size_t)nc, -1);
+  // pass 1: local levels (only the dependencies inside the chunk count), order of the rows, steps
+  flow_parallel_for(nc, threads, [&](int ic) {
+    const int c = order[ic];
+    FlowChunk &C = chunks[ic];
+    const int b = cnt[c], e = cnt[c + 1], m = e - b;
     int nl = 0, w = 0;
     for (int t = 0; t < m; ++t) {
       const int i = fwd ? rows[b + t] : rows[e - 1 - t];
@@ -94,70 +129,90 @@ inline std::string flow_build(int n, const int64_t *rowPtr, const int *colIdx, c
         if (!is_dep(i, col)) continue;
         ++deps;
         if (chunkOf[col] == c) l = std::max(l, lvl[col] + 1);
-        else if (fwd ? chunkOf[col] > c : chunkOf[col] < c)
-          return "row " + std::to_string(i) + " depends on row " + std::to_string(col) + " of a later chunk";
+        else if ((fwd ? chunkOf[col] > c : chunkOf[col] < c) && badRow[ic] < 0) { badRow[ic] = i; badCol[ic] = col; }
       }
       lvl[i] = l;
       nl = std::max(nl, l + 1);
       w = std::max(w, deps);
     }
     // counting sort by level, ascending row inside a level
-    lcount.assign((size_t)nl + 1, 0);
+    std::vector<int> lcount((size_t)nl + 1, 0);
     for (int t = b; t < e; ++t) ++lcount[(size_t)lvl[rows[t]] + 1];
     for (int l = 0; l < nl; ++l) lcount[l + 1] += lcount[l];
-    FlowChunk C{};
-    C.entOff = entTotal;
-    C.rowOff = rowOff;
-    C.m = m;
     C.w = w;
-    C.stepOff = (int)S.steps.size();
+    std::vector<int> &st = stepsOf[ic];
     for (int l = 0; l < nl; ++l)
-      for (int q = lcount[l]; q < lcount[l + 1]; q += FLOW_STEP) S.steps.push_back(q);
-    S.steps.push_back(m);
-    C.nSteps = (int)S.steps.size() - 1 - C.stepOff;
-    S.maxSteps = std::max(S.maxSteps, C.nSteps);
-    sorted.assign(lcount.begin(), lcount.end() - 1);
+      for (int q = lcount[l]; q < lcount[l + 1]; q += FLOW_STEP) st.push_back(q);
+    st.push_back(m);
+    C.nSteps = (int)st.size() - 1;
     for (int t = b; t < e; ++t) {
       const int i = rows[t];
-      const int q = sorted[lvl[i]]++;
+      const int q = lcount[lvl[i]]++;
       pos[i] = q;
-      S.rowOf[(size_t)rowOff + q] = i;
+      S.rowOf[(size_t)C.rowOff + q] = i;
     }
-    S.code.resize((size_t)(entTotal + (long long)w * m), FLOW_PAD);
-    S.src.resize((size_t)(entTotal + (long long)w * m), -1);
+  });
+  for (int ic = 0; ic < nc; ++ic)
+    if (badRow[ic] >= 0)
+      return "row " + std::to_string(badRow[ic]) + " depends on row " + std::to_string(badCol[ic]) + " of a later chunk";
+  long long entTotal = 0;
+  for (int ic = 0; ic < nc; ++ic) {
+    FlowChunk &C = chunks[ic];
+    C.entOff = entTotal;
+    entTotal += (long long)C.w * C.m;
+    C.stepOff = (int)S.steps.size();
+    S.steps.insert(S.steps.end(), stepsOf[ic].begin(), stepsOf[ic].end());
+    S.maxSteps = std::max(S.maxSteps, C.nSteps);
+    S.wMax = std::max(S.wMax, C.w);
+  }
+  S.code.assign((size_t)std::max<long long>(entTotal, 1), FLOW_PAD);
+  S.src.assign((size_t)std::max<long long>(entTotal, 1), -1);
+  // pass 2: the entries
+  std::vector<int> lookOf((size_t)nc, 0);
+  std::vector<long long> extOf((size_t)nc, 0);
+  flow_parallel_for(nc, threads, [&](int ic) {
+    const int c = order[ic];
+    const FlowChunk &C = chunks[ic];
+    const int b = cnt[c], e = cnt[c + 1], m = C.m;
     for (int t = b; t < e; ++t) {
       const int i = rows[t], q = pos[i];
       int kk = 0;
       for (int64_t k = rowPtr[i]; k < rowPtr[i + 1]; ++k) {
         const int col = colIdx[k];
         if (!is_dep(i, col)) continue;
-        const size_t idx = (size_t)(entTotal + (long long)kk * m + q);
+        const size_t idx = (size_t)(C.entOff + (long long)kk * m + q);
         S.src[idx] = k;
         if (chunkOf[col] == c) {
           const int back = q - pos[col];  // > 0: a lower level sorts first
           S.code[idx] = back;
-          S.maxLookback = std::max(S.maxLookback, back);
+          lookOf[ic] = std::max(lookOf[ic], back);
         } else {
           S.code[idx] = ~col;
-          visible[col] = 1;
-          ++S.nExternal;
+          ++extOf[ic];
         }
         ++kk;
       }
     }
-    S.wMax = std::max(S.wMax, w);
-    entTotal += (long long)w * m;
-    rowOff += m;
-    S.chunks.push_back(C);
+  });
+  for (int ic = 0; ic < nc; ++ic) {
+    S.maxLookback = std::max(S.maxLookback, lookOf[ic]);
+    S.nExternal += extOf[ic];
   }
-  if (S.code.empty()) { S.code.push_back(FLOW_PAD); S.src.push_back(-1); }
   // exchange slots in schedule order, then the entries of other chunks point at them
+  std::vector<char> visible((size_t)n, 0);
+  for (int c : S.code)
+    if (c < 0 && c != FLOW_PAD) visible[(size_t)~c] = 1;
   std::vector<int> slotOfRow((size_t)n, -1);
   S.pubOf.assign((size_t)n, -1);
   for (int p = 0; p < n; ++p)
     if (visible[S.rowOf[p]]) slotOfRow[S.rowOf[p]] = S.pubOf[p] = S.nVisible++;
-  for (int &c : S.code)
-    if (c < 0 && c != FLOW_PAD) c = ~slotOfRow[~c];
+  flow_parallel_for(nc, threads, [&](int ic) {
+    const FlowChunk &C = chunks[ic];
+    for (long long x = C.entOff, xe = C.entOff + (long long)C.w * C.m; x < xe; ++x) {
+      int &c = S.code[(size_t)x];
+      if (c < 0 && c != FLOW_PAD) c = ~slotOfRow[~c];
+    }
+  });
   return std::string();
 }
 

@@ -1,5 +1,5 @@
 // flowcheck.cpp -- CPU replay of the dataflow SGS schedule (nalu_amd/csrc/sgs_flow.hpp) against the
-// sequential sweeps, bit for bit.  Development aid: g++ -O2 -std=c++17 -I../nalu_amd/csrc flowcheck.cpp
+// sequential sweeps, bit for bit.  Development aid: g++ -O2 -std=c++17 -pthread -I../nalu_amd/csrc flowcheck.cpp
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -94,7 +94,7 @@ static int check(const char *name, const Csr &A, int chunkRows, int By, int Bz)
   for (int dir = 0; dir < 2; ++dir) {
     const bool fwd = dir == 0;
     FlowSchedule S;
-    std::string why = flow_build(n, A.rowPtr.data(), A.col.data(), chunkOf, T.nChunks, fwd, S);
+    std::string why = flow_build(n, A.rowPtr.data(), A.col.data(), chunkOf, T.nChunks, fwd, S, 1 + dir * 3);  // 1 and 4 threads
     if (!why.empty()) { printf("%s: %s chunking rejected: %s\n", name, fwd ? "fwd" : "bwd", why.c_str()); return 1; }
     int ring = 64;
     while (ring < S.maxLookback + FLOW_STEP) ring *= 2;

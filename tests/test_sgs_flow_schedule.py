@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_schedule_replays_the_sequential_sweeps(tmp_path):
     exe = str(tmp_path / "flowcheck")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "nalu_amd", "csrc"),
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-I", os.path.join(ROOT, "nalu_amd", "csrc"),
                     os.path.join(ROOT, "scripts", "flowcheck.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "all schedules replay the sequential sweeps bit for bit" in out, out
