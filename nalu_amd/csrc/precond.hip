@@ -835,11 +835,18 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     // both sweeps at once, each on half of the host threads (16 at most: a GPU's share of the node's cores)
     std::string why[2];
     {
-      std::thread other([&]() {
-        why[1] = flow_build(n, h->rowPtr.data(), h->colIdx.data(), chunkOf, T.nChunks, false, S[1], hostThreads / 2);
-      });
-      why[0] = flow_build(n, h->rowPtr.data(), h->colIdx.data(), chunkOf, T.nChunks, true, S[0], hostThreads / 2);
+      auto build = [&](int dir) {  // (an exception must not leave a thread: it would end the process)
+        try {
+          why[dir] = flow_build(n, h->rowPtr.data(), h->colIdx.data(), chunkOf, T.nChunks, dir == 0, S[dir], hostThreads / 2);
+        } catch (const std::exception &e) {
+          why[dir] = std::string("exception: ") + e.what();
+        }
+      };
+      std::thread other(build, 1);
+      build(0);
       other.join();
+      for (int dir = 0; dir < 2; ++dir)
+        NG_REQUIRE(why[dir].compare(0, 10, "exception:") != 0, NALU_GPU_EHIP, "sgs schedule (host): %s", why[dir].c_str());
     }
     bool ok = why[0].empty() && why[1].empty();
     for (int dir = 0; dir < 2 && ok; ++dir) ok = S[dir].maxLookback + FLOW_STEP <= 4096;

@@ -25,6 +25,7 @@
 #include <atomic>
 #include <climits>
 #include <cstdint>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -68,13 +69,21 @@ inline void flow_parallel_for(int count, int threads, F f)
     return;
   }
   std::atomic<int> next(0);
+  std::atomic<bool> failed(false);
+  std::exception_ptr error;  // the first exception of any thread, rethrown by the caller's thread
   auto work = [&]() {
-    for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) f(i);
+    try {
+      for (int i = next.fetch_add(1); i < count && !failed.load(); i = next.fetch_add(1)) f(i);
+    } catch (...) {
+      bool expected = false;
+      if (failed.compare_exchange_strong(expected, true)) error = std::current_exception();
+    }
   };
   std::vector<std::thread> pool;
   for (int t = 1; t < threads; ++t) pool.emplace_back(work);
   work();
   for (std::thread &t : pool) t.join();
+  if (error) std::rethrow_exception(error);
 }
 
 // chunkOf[i] = position of row i's chunk in the FORWARD processing order (0 .. nChunks-1); the
