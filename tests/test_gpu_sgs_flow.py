@@ -121,7 +121,7 @@ def test_dataflow_sweeps_equal_level_sweeps_bit_for_bit(G, torch, oracle, dims, 
 
 
 def test_dataflow_sweeps_repeat_and_survive_a_converged_solve(G, torch, oracle):
-    """The result vectors double as 'not computed yet' flags and are re-armed by the sweeps themselves:
+    """The exchange buffers double as 'not computed yet' flags and are cleared before every sweep:
     many applications in one solve, a solve that converges (later kernels return early on the device's
     done flag), host-driven methods (no done flag) and a second solve on new values must all agree with
     the level sweeps."""
