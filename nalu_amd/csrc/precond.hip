@@ -747,9 +747,8 @@ int sgs_mode()
   if (getenv("NG_SGS_INPLACE") && atoi(getenv("NG_SGS_INPLACE")) != 0) return SGS_INPLACE;
   return SGS_FLOW;
 }
-// rows of at most 4 entries a side (7-point graphs): look-ahead of 2, 4 or 8 steps (NG_SGS_DEPTH);
+// rows of at most 4 entries a side (7-point graphs): look-ahead of 2 or 4 steps (NG_SGS_DEPTH);
 // up to 16 (27-point graphs): 2 steps
-using FlowA8 = FlowCfg<8, 4, 4>;
 using FlowA4 = FlowCfg<4, 4, 2>;
 using FlowA2 = FlowCfg<2, 4, 2>;
 using FlowB = FlowCfg<2, 16, 1>;
@@ -787,9 +786,7 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *o
   }
   int *err = (int *)(h->dReduce + REDUCE_CAP) + 2;
   const dim3 block(64 * (2 + FLOW_LOADERS));
-  if (fd.depth == 8)
-    k_flow_sweep<FWD, 8, 4, 4><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
-  else if (fd.depth == 4)
+  if (fd.depth == 4 && fd.wMax <= 4)
     k_flow_sweep<FWD, 4, 4, 2><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
   else if (fd.wMax <= 4)
     k_flow_sweep<FWD, 2, 4, 2><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
@@ -822,7 +819,7 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
   if (n == 0) return NALU_GPU_OK;
   int chunkRows = getenv("NG_SGS_CHUNK") ? atoi(getenv("NG_SGS_CHUNK")) : 1024;
   chunkRows = std::min(std::max(chunkRows, 64), 2048);
-  int By = 8, Bz = 8;
+  int By = 6, Bz = 6;  // (profiles/r2_sgsflow_tiles.json: 5 x 6 ... 6 x 7 are within 1 %)
   if (const char *t = getenv("NG_SGS_TILE")) {
     if (sscanf(t, "%d,%d", &By, &Bz) != 2) By = Bz = 0;  // anything else: contiguous chunks only
   }
@@ -861,10 +858,9 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     while (ring < s.maxLookback + FLOW_STEP + FLOW_PUB_WINDOW) ring *= 2;
     if (ring > 8192 || s.wMax > 16) return NALU_GPU_OK;
     int depth = getenv("NG_SGS_DEPTH") ? atoi(getenv("NG_SGS_DEPTH")) : 2;
-    depth = depth >= 8 ? 8 : depth >= 4 ? 4 : 2;
+    depth = depth >= 4 ? 4 : 2;  // (8 steps of look-ahead no longer fit the instruction cache and the LDS)
     fd.depth = s.wMax <= 4 ? depth : 2;
     fd.ldsBytes = s.wMax > 4       ? FlowB::lds_bytes(ring, s.maxSteps)
-                  : fd.depth == 8 ? FlowA8::lds_bytes(ring, s.maxSteps)
                   : fd.depth == 4 ? FlowA4::lds_bytes(ring, s.maxSteps)
                                   : FlowA2::lds_bytes(ring, s.maxSteps);
     if (getenv("NG_SGS_LDS_PAD")) fd.ldsBytes += (size_t)atoi(getenv("NG_SGS_LDS_PAD"));  // development aid: fewer workgroups per CU
@@ -904,8 +900,6 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     s = FlowSchedule();
   }
   NG_HIP(hipMalloc(&h->dFlowT, sizeof(double) * (size_t)n));
-  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
-  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
