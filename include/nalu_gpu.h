@@ -270,7 +270,8 @@ int nalu_gpu_check_system(nalu_gpu_linsys *h, nalu_gpu_check_info *info);
 /* realm_.debug() (src/TpetraLinearSystem.C:1716-1721): when on, nalu_gpu_solve runs the two checks
  * first and fails with NALU_GPU_EINVAL ("bad LHS" / "ERROR checkForZeroRow in solve()") instead of
  * solving.  Independently of this switch a zero, missing or non-finite diagonal under a
- * relaxation preconditioner is always an error (single rank), never a silent inf. */
+ * relaxation preconditioner is always an error, never a silent inf.  Either verdict is summed over the
+ * ranks of the comm first, so that all ranks of a multi-rank solve return the error together. */
 int nalu_gpu_set_debug(nalu_gpu_linsys *h, int enabled);
 
 /* ---- building blocks exposed for measurement and parity (Tpetra call sites:
@@ -332,6 +333,15 @@ int nalu_gpu_project_nodal_velocity(nalu_gpu_linsys *h, int64_t n, double dt, do
                                     const unsigned char *projected_dev,
                                     nalu_gpu_vec3 velocity_dev);
 
+/* MixtureFractionEquationSystem::update_and_clip (src/MixtureFractionEquationSystem.C:942-1013):
+ * z += dz on n nodes (the reference: owned and shared), the un-clipped sum kept in
+ * z_unfiltered_dev (mixFracUF_, may be NULL), z clipped to [0 - delta_clip, 1 + delta_clip].
+ * clip_info (host, may be NULL = no diagnostics, no host synchronisation): {nodes clipped below,
+ * nodes clipped above, smallest and largest un-clipped value (+1e16 / -1e16 when nothing was
+ * clipped)} of this rank; the all-reduce of :991-1007 (outputClippingDiag_) is the caller's. */
+int nalu_gpu_update_and_clip(nalu_gpu_linsys *h, int64_t n, const double *dz_dev, double *z_dev,
+                             double *z_unfiltered_dev, double delta_clip, double clip_info[4]);
+
 /* ---- multi-GPU plumbing (Tpetra Import/Export + all-reduce equivalents) ----------------
  * The library packs/unpacks and reduces on the device; moving bytes between GPUs is the
  * host's job (RCCL through torch.distributed, or ncclSend/Recv from a C++ host).
@@ -378,6 +388,24 @@ int nalu_gpu_get_comm_buffers(nalu_gpu_linsys *h, double **send_buf_dev, int64_t
  * src/LinearSystem.C:111-116; Tpetra Import inside CrsMatrix::apply) */
 int nalu_gpu_halo_exchange(nalu_gpu_linsys *h, double *vec_dev /* n_cols */);
 
+/* stk::mesh::parallel_sum (src/AssembleNodalGradAlgorithmDriver.C:111 for the nodal gradient,
+ * src/ComputeGeometryAlgorithmDriver.C:126-133 for dual_nodal_volume and edge_area_vector): every
+ * rank that shares an entity -- holds it through elements of its own -- gets the sum of all
+ * sharers' values.  A share plan lists, for every neighbour of the halo plan (same order; a list
+ * may be empty), the local indices of the entities (nodes, or edges in the graph's edge order)
+ * shared with that neighbour, in the same order on both sides (ascending global id, as STK's comm
+ * lists); an entity shared by several ranks is listed for each of them.  The values are exchanged
+ * once (the comm's exchange_rows) and added in ascending rank order over all sharers, the rank's
+ * own value at its own place: the same bits on every sharer.  Ghost copies (entities a rank holds
+ * only because an owned node's row needs them) are not shared: nalu_gpu_halo_exchange updates
+ * those.  fields_dev: n_fields (<= 16) device arrays indexed by the plan's entity index. */
+typedef struct nalu_gpu_share_plan nalu_gpu_share_plan;
+int nalu_gpu_share_plan_create(nalu_gpu_linsys *h, const int *offsets /* n_neighbors + 1 */,
+                               const int *local_ids, int64_t n_entities, nalu_gpu_share_plan **out);
+int nalu_gpu_share_plan_destroy(nalu_gpu_share_plan *p);
+int nalu_gpu_parallel_sum(nalu_gpu_linsys *h, nalu_gpu_share_plan *p, int n_fields,
+                          double *const *fields_dev);
+
 /* ---- timers: EquationSystem's buckets (src/EquationSystem.C:270-292) measured with HIP
  * events on the handle's stream. */
 enum {
@@ -392,7 +420,8 @@ int nalu_gpu_get_timer_launches(nalu_gpu_linsys *h, int which, int64_t *launched
 /* Schedule of the exact SGS sweeps (preconditioner "sgs"), valid after the first solve with it.  No counterpart
  * in the reference (Ifpack2 sweeps rows sequentially on the host).  out[0]: 1 = dataflow sweeps (one launch per
  * sweep), -1 = one launch per level (rows wider than the dataflow kernel takes, or NG_SGS_MODE=levels|inplace),
- * 0 = not built yet; out[1]: 1 = lattice tiles, 0 = contiguous row chunks; out[2]: chunks; out[3]: most steps of
+ * -2 = one launch per level because a dataflow sweep gave up waiting in an earlier solve (that solve was redone
+ * on the level schedule inside nalu_gpu_solve: same bits, nothing to wait for), 0 = not built yet; out[1]: 1 = lattice tiles, 0 = contiguous row chunks; out[2]: chunks; out[3]: most steps of
  * a chunk; out[4]: widest row (entries one side of the diagonal); out[5]: LDS ring (rows); out[6], out[7]: lines
  * and planes per tile */
 int nalu_gpu_get_sgs_schedule(nalu_gpu_linsys *h, int out[8]);

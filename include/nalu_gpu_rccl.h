@@ -37,6 +37,13 @@ int nalu_gpu_rccl_world_destroy(nalu_gpu_rccl_world *w);
  * neighbour ranks and offsets are read back from the handle).  The comm must be destroyed before
  * the system and the world. */
 int nalu_gpu_rccl_attach(nalu_gpu_rccl_world *w, nalu_gpu_linsys *h, nalu_gpu_rccl_comm **out);
+/* The same with flags.  NALU_GPU_RCCL_ALLOW_SELF_NEIGHBOUR: a halo neighbour may be the rank itself
+ * (ncclSend / ncclRecv to the own rank inside one group; the k-th send to oneself is matched with
+ * the k-th receive from oneself).  That is what a mesh that is periodic across the rank's own
+ * boundary needs -- and the way the one-GPU test box makes the grouped send / recv, the side
+ * stream and its event hand-over really run on RCCL (tests/test_distributed.py, loop-back). */
+enum { NALU_GPU_RCCL_ALLOW_SELF_NEIGHBOUR = 1 };
+int nalu_gpu_rccl_attach_flags(nalu_gpu_rccl_world *w, nalu_gpu_linsys *h, int flags, nalu_gpu_rccl_comm **out);
 int nalu_gpu_rccl_detach(nalu_gpu_rccl_comm *c);
 /* message of the calling thread's last failure in this library */
 const char *nalu_gpu_rccl_last_error(void);

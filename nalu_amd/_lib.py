@@ -33,6 +33,7 @@ SYMBOLS = [
     "nalu_gpu_set_comm", "nalu_gpu_set_callback_error", "nalu_gpu_get_halo_plan", "nalu_gpu_set_assembly_mode", "nalu_gpu_set_edge_ownership", "nalu_gpu_get_comm_buffers", "nalu_gpu_halo_exchange",
     "nalu_gpu_set_profiling", "nalu_gpu_get_timer", "nalu_gpu_get_timer_launches", "nalu_gpu_reset_timers",
     "nalu_gpu_synchronize", "nalu_gpu_get_layout_info", "nalu_gpu_suggest_edge_order", "nalu_gpu_check_system", "nalu_gpu_set_debug", "nalu_gpu_dot_static", "nalu_gpu_get_sgs_schedule",
+    "nalu_gpu_update_and_clip", "nalu_gpu_share_plan_create", "nalu_gpu_share_plan_destroy", "nalu_gpu_parallel_sum",
 ]
 
 
@@ -175,6 +176,10 @@ def load():
         "nalu_gpu_check_system": [vp, P(CheckInfo)],
         "nalu_gpu_set_debug": [vp, ci],
         "nalu_gpu_dot_static": [ci, vp, vp, vp, i64, vp],
+        "nalu_gpu_update_and_clip": [vp, i64, vp, vp, vp, dbl, vp],
+        "nalu_gpu_share_plan_create": [vp, vp, vp, i64, P(vp)],
+        "nalu_gpu_share_plan_destroy": [vp],
+        "nalu_gpu_parallel_sum": [vp, vp, ci, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

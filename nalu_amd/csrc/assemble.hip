@@ -5,6 +5,8 @@
 // arithmetic is written operation by operation like the reference loops so that, with FP
 // contraction off, results are bit-identical to the CPU oracle on identically ordered
 // meshes.
+#include <cstring>
+
 #include "internal.hpp"
 
 using namespace nalu_gpu;
@@ -1104,8 +1106,71 @@ __global__ __launch_bounds__(256) void k_project_velocity(long long n, double pr
   const_cast<double *>(u.z)[i] -= fac * (gNew.z[i] - gOld.z[i]);
 }
 
+// src/MixtureFractionEquationSystem.C:966-986.  diag (null: no diagnostics): [0], [1] nodes clipped
+// below / above, [2], [3] the smallest / largest un-clipped value as order-preserving 64-bit keys
+__device__ __forceinline__ unsigned long long ord_key(double v)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__global__ __launch_bounds__(256) void k_update_and_clip(long long n, const double *__restrict__ dz,
+                                                          double *__restrict__ z, double *__restrict__ zUF,
+                                                          double lowBound, double highBound,
+                                                          unsigned long long *__restrict__ diag)
+{
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = z[i] + dz[i];
+  if (zUF) zUF[i] = v;
+  if (v < lowBound) {
+    if (diag) { atomicAdd(diag, 1ULL); atomicMin(diag + 2, ord_key(v)); }
+    v = lowBound;
+  } else if (v > highBound) {
+    if (diag) { atomicAdd(diag + 1, 1ULL); atomicMax(diag + 3, ord_key(v)); }
+    v = highBound;
+  }
+  z[i] = v;
+}
+
 }  // namespace
 
+
+extern "C" int nalu_gpu_update_and_clip(nalu_gpu_linsys *h, int64_t n, const double *dz_dev, double *z_dev,
+                                        double *z_unfiltered_dev, double delta_clip, double clip_info[4])
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(n >= 0 && (n == 0 || (dz_dev && z_dev)), NALU_GPU_EINVAL, "update_and_clip: bad arguments");
+  const double lowBound = 0.0 - delta_clip, highBound = 1.0 + delta_clip;  // (:946-947)
+  unsigned long long *dDiag = nullptr;
+  if (clip_info) {  // (the head of the reduce buffer: nothing of the solver is in flight between solves)
+    dDiag = (unsigned long long *)h->dReduce;
+    unsigned long long *pin = (unsigned long long *)((char *)h->hPinned + 3584);
+    pin[0] = pin[1] = 0ULL;
+    pin[2] = ~0ULL;
+    pin[3] = 0ULL;
+    NG_HIP(hipMemcpyAsync(dDiag, pin, 4 * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+  }
+  if (n)
+    k_update_and_clip<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(n, dz_dev, z_dev, z_unfiltered_dev, lowBound,
+                                                                          highBound, dDiag);
+  NG_HIP(hipGetLastError());
+  if (clip_info) {
+    unsigned long long *pin = (unsigned long long *)((char *)h->hPinned + 3584);
+    NG_HIP(hipMemcpyAsync(pin, dDiag, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    NG_HIP(hipStreamSynchronize(h->stream));
+    auto unkey = [](unsigned long long k) {
+      const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
+      double v;
+      memcpy(&v, &b, sizeof(v));
+      return v;
+    };
+    clip_info[0] = (double)pin[0];
+    clip_info[1] = (double)pin[1];
+    clip_info[2] = pin[0] ? unkey(pin[2]) : +1.0e16;  // (:949-950)
+    clip_info[3] = pin[1] ? unkey(pin[3]) : -1.0e16;
+  }
+  return NALU_GPU_OK;
+}
 
 extern "C" int nalu_gpu_assemble_continuity_edges(nalu_gpu_linsys *h,
                                                   const nalu_gpu_continuity_fields *f, double dt,

@@ -182,7 +182,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dBurst); NG_FREE(h->dMarch); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   for (auto &fd : h->flow) {
-    NG_FREE(fd.dChunks); NG_FREE(fd.dRowOf); NG_FREE(fd.dPubOf); NG_FREE(fd.dXch); NG_FREE(fd.dCode); NG_FREE(fd.dSteps); NG_FREE(fd.dSrc); NG_FREE(fd.dVal);
+    NG_FREE(fd.dTicket); NG_FREE(fd.dChunks); NG_FREE(fd.dRowOf); NG_FREE(fd.dPubOf); NG_FREE(fd.dXch); NG_FREE(fd.dCode); NG_FREE(fd.dSteps); NG_FREE(fd.dSrc); NG_FREE(fd.dVal);
   }
   NG_FREE(h->dFlowT);
   NG_FREE(h->dY); NG_FREE(h->dList); NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf);
@@ -894,6 +894,10 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
     NG_HIP(hipMemcpy(h->dEdgeR, eR.data(), sizeof(int) * (size_t)h->nEdges, hipMemcpyHostToDevice));
     if (h->asmMode == NALU_GPU_ASSEMBLY_EXPORT_SHARED_ROWS) {
       if (h->edgeOwnedHost.empty()) h->edgeOwnedHost.assign((size_t)h->nEdges, 1);
+      // (an edge block registered after nalu_gpu_set_edge_ownership has no entry in the list)
+      NG_REQUIRE((int64_t)h->edgeOwnedHost.size() == h->nEdges, NALU_GPU_ESTATE,
+                 "edge ownership was given for %lld edges but the graph has %lld: call nalu_gpu_set_edge_ownership "
+                 "after the last edge block", (long long)h->edgeOwnedHost.size(), (long long)h->nEdges);
       NG_HIP(hipMalloc(&h->dEdgeOwned, (size_t)h->nEdges));
       NG_HIP(hipMemcpy(h->dEdgeOwned, h->edgeOwnedHost.data(), (size_t)h->nEdges, hipMemcpyHostToDevice));
     }
@@ -1196,6 +1200,28 @@ extern "C" int nalu_gpu_get_solution(nalu_gpu_linsys *h, double *x)
   return NALU_GPU_OK;
 }
 
+// ------------------------------------------------------- collective error verdicts
+// Collective entry points (solve, loadComplete in export mode) must leave on every rank together: a
+// rank that returns an error by itself leaves the others inside the next all-reduce / exchange for
+// good.  Local error counts therefore go through the comm's all-reduce before anyone decides:
+// vals[0..n) (non-negative counts, n <= 8) become their sums over the ranks.  Without a comm this
+// is a no-op.  Uses the head of the reduce buffer: call it between, not inside, the solver's
+// reductions.
+int nalu_gpu::agree_counts(nalu_gpu_linsys *h, int n, long long *vals)
+{
+  if (!h->hasComm) return NALU_GPU_OK;
+  NG_REQUIRE(n >= 1 && n <= 8, NALU_GPU_EINVAL, "agree_counts: n = %d", n);
+  double *pin = (double *)((char *)h->hPinned + 3584);
+  for (int i = 0; i < n; ++i) pin[i] = (double)vals[i];
+  NG_HIP(hipMemcpyAsync(h->dReduce, pin, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  NG_REQUIRE(h->comm.allreduce_sum(h->comm.ctx, n, h->stream) == 0, NALU_GPU_EHIP,
+             "allreduce_sum callback failed: %s", callback_error());
+  NG_HIP(hipMemcpyAsync(pin, h->dReduce, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  NG_HIP(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; ++i) vals[i] = (long long)(pin[i] + 0.5);
+  return NALU_GPU_OK;
+}
+
 // ------------------------------------------------------------- zero / sumInto / BC
 // zeroSystem is lazy: it only marks matrix and rhs as logically zero.  The first bulk
 // row-gather assembly then *stores* its rows (no memset, no read-modify-write); any other
@@ -1204,6 +1230,7 @@ extern "C" int nalu_gpu_zero_system(nalu_gpu_linsys *h)
 {
   NG_FINALIZED(h);
   h->lazyZero = true;
+  h->exportedSinceZero = false;
   // sln_->putScalar(0) (src/TpetraLinearSystem.C:1347): the solve starts from x0 = 0 itself
   return NALU_GPU_OK;
 }
@@ -1369,7 +1396,15 @@ extern "C" int nalu_gpu_load_complete(nalu_gpu_linsys *h)
   // owner-computes mode every owned row was assembled completely by its owner (cut edges are
   // duplicated on both sides), so there is nothing to move; only pending zeros are made real.
   NG_TRY(materialize_zero(h));
-  if (h->asmMode == NALU_GPU_ASSEMBLY_EXPORT_SHARED_ROWS) return export_shared_rows(h);
+  if (h->asmMode == NALU_GPU_ASSEMBLY_EXPORT_SHARED_ROWS) {
+    // a second loadComplete without a zeroSystem in between would export -- and add -- the shared rows
+    // twice (Tpetra: fillComplete on a matrix that is already fill-complete throws)
+    NG_REQUIRE(!h->exportedSinceZero, NALU_GPU_ESTATE,
+               "load_complete: the shared-not-owned rows were already exported since the last zeroSystem "
+               "(src/TpetraLinearSystem.C:1686-1707 runs once per assembly)");
+    NG_TRY(export_shared_rows(h));
+    h->exportedSinceZero = true;
+  }
   return NALU_GPU_OK;
 }
 
@@ -1436,6 +1471,13 @@ int ensure_export_plan(nalu_gpu_linsys *h)
              "export mode needs a comm with exchange_rows (nalu_gpu_set_comm) and the halo plan");
   NG_REQUIRE(h->recvCount == h->nCols - h->nOwned, NALU_GPU_ESTATE, "export mode: set the halo plan first");
   const int nN = h->nNbr, nO = h->nOwned;
+  // What one rank finds wrong with its own lists must not make it leave while the others are inside
+  // the exchanges below: the first such finding is kept, the exchanges run all the same (without the
+  // offending rows), and the verdict is all-reduced at the end so that every rank returns together.
+  char localErr[512] = "";
+  auto complain = [&](const char *fmt, auto... args) {
+    if (!localErr[0]) snprintf(localErr, sizeof(localErr), fmt, args...);
+  };
   // shared rows by owner, in neighbour order (ascending local id = ascending global id inside)
   std::vector<std::vector<int>> rowsTo((size_t)nN);
   int Wloc = 0;
@@ -1443,8 +1485,10 @@ int ensure_export_plan(nalu_gpu_linsys *h)
     const int lid = nO + s;
     int p = 0;
     while (p < nN && h->nbrRanks[p] != h->owners[lid]) ++p;
-    NG_REQUIRE(p < nN, NALU_GPU_EINVAL, "shared node %d is owned by rank %d, which is no halo neighbour", lid,
-               h->owners[lid]);
+    if (p == nN) {
+      complain("shared node %d is owned by rank %d, which is no halo neighbour", lid, h->owners[lid]);
+      continue;
+    }
     rowsTo[p].push_back(lid);
     Wloc = std::max(Wloc, (int)(h->rowPtr[lid + 1] - h->rowPtr[lid]));
   }
@@ -1483,10 +1527,11 @@ int ensure_export_plan(nalu_gpu_linsys *h)
       for (int64_t k = 0; k < len; ++k) m[2 + k] = (double)h->gids[h->colIdx[b + k]];
     }
   NG_TRY(exchange_host(h, ms, mso, mr, mro));
-  // 3. where every received number goes
+  // 3. where every received number goes.  (Global id -> local node, an owned node first: a mesh
+  // that is periodic across the rank's own boundary holds copies of its own nodes.)
   std::unordered_map<int64_t, int> lidOf;
   lidOf.reserve((size_t)h->nCols * 2);
-  for (int i = 0; i < h->nCols; ++i) lidOf[h->gids[i]] = i;
+  for (int i = 0; i < h->nCols; ++i) lidOf.emplace(h->gids[i], i);
   std::vector<int> recvRow;
   std::vector<long long> recvPos((size_t)h->expRecvPosOff[nN], -1);
   long long missing = 0;
@@ -1495,25 +1540,43 @@ int ensure_export_plan(nalu_gpu_linsys *h)
     for (int q = 0; q < h->expRecvRows[p]; ++q) {
       const double *m = &mr[(size_t)mro[p] + (size_t)q * (W + 2)];
       auto it = lidOf.find((int64_t)m[0]);
-      NG_REQUIRE(it != lidOf.end() && it->second < nO, NALU_GPU_EINVAL,
-                 "export: rank %d sent a row of global id %lld, which this rank does not own", h->nbrRanks[p],
+      if (it == lidOf.end() || it->second >= nO) {
+        complain("export: rank %d sent a row of global id %lld, which this rank does not own", h->nbrRanks[p],
                  (long long)m[0]);
+        recvRow.push_back(0);
+        continue;
+      }
       const int row = it->second;
       recvRow.push_back(row);
       const int *cb = &h->colIdx[h->rowPtr[row]], *ce = &h->colIdx[h->rowPtr[row + 1]];
       const long long off = h->hSliceOff[row / SELL_C];
       for (int k = 0; k < (int)m[1]; ++k) {
-        auto ic = lidOf.find((int64_t)m[2 + k]);
-        const int *f = ic == lidOf.end() ? ce : std::lower_bound(cb, ce, ic->second);
-        if (f == ce || *f != ic->second) { ++missing; continue; }
+        // (a column's global id may name an owned node and a copy of it: any of them that is in the row)
+        const int64_t cg = (int64_t)m[2 + k];
+        const int *f = ce;
+        auto ic = lidOf.find(cg);
+        if (ic != lidOf.end()) {
+          f = std::lower_bound(cb, ce, ic->second);
+          if (f == ce || *f != ic->second) {
+            f = ce;
+            for (const int *c = cb; c < ce; ++c)
+              if (h->gids[*c] == cg) { f = c; break; }
+          }
+        }
+        if (f == ce) { ++missing; continue; }
         recvPos[(size_t)h->expRecvPosOff[p] + (size_t)q * W + k] = off + (long long)(f - cb) * SELL_C + row % SELL_C;
       }
     }
   }
-  NG_REQUIRE(missing == 0, NALU_GPU_EINVAL,
-             "export: %lld entries of received rows have no slot in the owner's graph: pass every edge that "
+  if (missing)
+    complain("export: %lld entries of received rows have no slot in the owner's graph: pass every edge that "
              "touches an owned node to the graph builders (the reference exchanges graph rows at finalize)",
              missing);
+  long long bad[1] = {localErr[0] ? 1 : 0};
+  NG_TRY(agree_counts(h, 1, bad));
+  if (bad[0])
+    return set_error(NALU_GPU_EINVAL, "%s",
+                     localErr[0] ? localErr : "export: another rank found its shared rows inconsistent with the halo plan");
   NG_FREE(h->dExpSendRow); NG_FREE(h->dExpRecvRow); NG_FREE(h->dExpRecvPos); NG_FREE(h->dExpSend); NG_FREE(h->dExpRecv);
   NG_HIP(hipMalloc(&h->dExpSendRow, sizeof(int) * std::max<size_t>(sendRow.size(), 1)));
   NG_HIP(hipMalloc(&h->dExpRecvRow, sizeof(int) * std::max<size_t>(recvRow.size(), 1)));
@@ -1783,4 +1846,154 @@ extern "C" int nalu_gpu_halo_exchange(nalu_gpu_linsys *h, double *vec_dev)
   NG_FINALIZED(h);
   NG_REQUIRE(vec_dev, NALU_GPU_EINVAL, "null vector");
   return halo_exchange(h, vec_dev);
+}
+
+// ---------------------------------------------------------------- parallel_sum
+// stk::mesh::parallel_sum (src/AssembleNodalGradAlgorithmDriver.C:111, src/ComputeGeometryAlgorithmDriver.C:
+// 126-133): every sharer of an entity ends up with the sum of all sharers' values.  Here: pack the
+// shared entities' values per neighbour, one neighbour exchange (exchange_rows), then the sum
+// 0 + v_r1 + v_r2 + ... over ALL sharers in ascending rank order, the rank's own value at its own
+// place -- the same expression on every sharer, hence the same bits everywhere (STK sums on the
+// owner and sends the result back; the effect is the same).
+struct nalu_gpu_share_plan {
+  nalu_gpu_linsys *h = nullptr;
+  int64_t nEntities = 0, nList = 0, nUniq = 0;
+  std::vector<int> off;   // per halo neighbour
+  int *dIds = nullptr;    // the lists, neighbour after neighbour
+  int *dUniq = nullptr;   // every shared entity once
+  double *dSend = nullptr, *dRecv = nullptr, *dStash = nullptr;
+  int cap = 0;            // fields the buffers hold
+};
+
+namespace {
+constexpr int PS_MAX_FIELDS = 16;
+struct PsFields { double *f[PS_MAX_FIELDS]; };
+
+__global__ void k_ps_pack(long long n, const int *__restrict__ ids, PsFields F, int nF, double *__restrict__ out)
+{
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int id = ids[i];
+  for (int f = 0; f < nF; ++f) out[i * nF + f] = F.f[f][id];
+}
+// own values aside, the entity zeroed: the sum starts from 0 on every sharer
+__global__ void k_ps_stash(long long n, const int *__restrict__ uniq, PsFields F, int nF, double *__restrict__ stash)
+{
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int id = uniq[i];
+  for (int f = 0; f < nF; ++f) {
+    stash[i * nF + f] = F.f[f][id];
+    F.f[f][id] = 0.0;
+  }
+}
+// one sharer's values added (an entity appears at most once in a list)
+__global__ void k_ps_add(long long n, const int *__restrict__ ids, PsFields F, int nF, const double *__restrict__ in)
+{
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int id = ids[i];
+  for (int f = 0; f < nF; ++f) F.f[f][id] += in[i * nF + f];
+}
+}  // namespace
+
+extern "C" int nalu_gpu_share_plan_create(nalu_gpu_linsys *h, const int *offsets, const int *local_ids,
+                                          int64_t n_entities, nalu_gpu_share_plan **out)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(out && n_entities >= 0, NALU_GPU_EINVAL, "share plan: bad arguments");
+  const int nN = h->nNbr;
+  NG_REQUIRE(nN == 0 || offsets, NALU_GPU_EINVAL, "share plan: one list per halo neighbour (set the halo plan first)");
+  const int64_t nl = nN ? offsets[nN] : 0;
+  NG_REQUIRE(nl == 0 || local_ids, NALU_GPU_EINVAL, "share plan: null list");
+  std::vector<int> uniq;
+  for (int p = 0; p < nN; ++p) {
+    NG_REQUIRE(offsets[p] <= offsets[p + 1] && offsets[0] == 0, NALU_GPU_EINVAL, "share plan: offsets must start at 0 and not decrease");
+    std::vector<int> one(local_ids + offsets[p], local_ids + offsets[p + 1]);
+    for (int id : one)
+      NG_REQUIRE(id >= 0 && id < n_entities, NALU_GPU_EINVAL, "share plan: entity %d outside [0,%lld)", id, (long long)n_entities);
+    std::sort(one.begin(), one.end());
+    NG_REQUIRE(std::adjacent_find(one.begin(), one.end()) == one.end(), NALU_GPU_EINVAL,
+               "share plan: an entity is listed twice for neighbour rank %d", h->nbrRanks[p]);
+    uniq.insert(uniq.end(), one.begin(), one.end());
+  }
+  std::sort(uniq.begin(), uniq.end());
+  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+  nalu_gpu_share_plan *P = new nalu_gpu_share_plan();
+  P->h = h;
+  P->nEntities = n_entities;
+  P->nList = nl;
+  P->nUniq = (int64_t)uniq.size();
+  if (nN) P->off.assign(offsets, offsets + nN + 1);
+  else P->off.assign(1, 0);
+  *out = P;  // (released by the caller also when one of the copies below fails)
+  NG_HIP(hipMalloc(&P->dIds, sizeof(int) * (size_t)std::max<int64_t>(nl, 1)));
+  NG_HIP(hipMalloc(&P->dUniq, sizeof(int) * std::max<size_t>(uniq.size(), 1)));
+  if (nl) NG_HIP(hipMemcpy(P->dIds, local_ids, sizeof(int) * (size_t)nl, hipMemcpyHostToDevice));
+  if (!uniq.empty()) NG_HIP(hipMemcpy(P->dUniq, uniq.data(), sizeof(int) * uniq.size(), hipMemcpyHostToDevice));
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_share_plan_destroy(nalu_gpu_share_plan *P)
+{
+  if (!P) return NALU_GPU_OK;
+  nalu_gpu::DeviceGuard ngGuard_(P->h->device);
+  (void)hipStreamSynchronize(P->h->stream);
+  NG_FREE(P->dIds); NG_FREE(P->dUniq); NG_FREE(P->dSend); NG_FREE(P->dRecv); NG_FREE(P->dStash);
+  delete P;
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_parallel_sum(nalu_gpu_linsys *h, nalu_gpu_share_plan *P, int n_fields,
+                                     double *const *fields_dev)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(P && P->h == h, NALU_GPU_EINVAL, "parallel_sum: the plan belongs to another linear system");
+  NG_REQUIRE(n_fields >= 1 && n_fields <= PS_MAX_FIELDS && fields_dev, NALU_GPU_EINVAL,
+             "parallel_sum: 1..%d fields per call (got %d)", PS_MAX_FIELDS, n_fields);
+  PsFields F;
+  for (int f = 0; f < n_fields; ++f) {
+    NG_REQUIRE(fields_dev[f], NALU_GPU_EINVAL, "parallel_sum: field %d is null", f);
+    F.f[f] = fields_dev[f];
+  }
+  const int nN = h->nNbr;
+  if (nN == 0) return NALU_GPU_OK;  // one rank: nothing is shared
+  NG_REQUIRE((int)P->off.size() == nN + 1, NALU_GPU_ESTATE, "parallel_sum: the halo plan changed since the share plan was made");
+  NG_REQUIRE(h->hasComm && h->comm.exchange_rows, NALU_GPU_ESTATE,
+             "parallel_sum needs a comm with exchange_rows (nalu_gpu_set_comm)");
+  if (n_fields > P->cap) {
+    NG_HIP(hipStreamSynchronize(h->stream));
+    NG_FREE(P->dSend); NG_FREE(P->dRecv); NG_FREE(P->dStash);
+    const size_t nb = sizeof(double) * (size_t)std::max<int64_t>(P->nList, 1) * n_fields;
+    NG_HIP(hipMalloc(&P->dSend, nb));
+    NG_HIP(hipMalloc(&P->dRecv, nb));
+    NG_HIP(hipMalloc(&P->dStash, sizeof(double) * (size_t)std::max<int64_t>(P->nUniq, 1) * n_fields));
+    P->cap = n_fields;
+  }
+  auto grid = [](long long n) { return (unsigned)((n + 255) / 256); };
+  if (P->nList) k_ps_pack<<<grid(P->nList), 256, 0, h->stream>>>(P->nList, P->dIds, F, n_fields, P->dSend);
+  NG_HIP(hipGetLastError());
+  std::vector<int64_t> off((size_t)nN + 1);
+  for (int p = 0; p <= nN; ++p) off[p] = (int64_t)P->off[p] * n_fields;
+  NG_REQUIRE(h->comm.exchange_rows(h->comm.ctx, P->dSend, off.data(), P->dRecv, off.data(), h->stream) == 0,
+             NALU_GPU_EHIP, "exchange_rows callback failed: %s", callback_error());
+  if (P->nUniq) k_ps_stash<<<grid(P->nUniq), 256, 0, h->stream>>>(P->nUniq, P->dUniq, F, n_fields, P->dStash);
+  // ascending rank order, this rank at its own place
+  std::vector<int> order((size_t)nN);
+  for (int p = 0; p < nN; ++p) order[p] = p;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->nbrRanks[a] < h->nbrRanks[b]; });
+  bool ownDone = false;
+  auto addOwn = [&]() {
+    if (!ownDone && P->nUniq) k_ps_add<<<grid(P->nUniq), 256, 0, h->stream>>>(P->nUniq, P->dUniq, F, n_fields, P->dStash);
+    ownDone = true;
+  };
+  for (int q = 0; q < nN; ++q) {
+    const int p = order[q];
+    if (h->nbrRanks[p] > h->myRank) addOwn();
+    const long long n = P->off[p + 1] - P->off[p];
+    if (n) k_ps_add<<<grid(n), 256, 0, h->stream>>>(n, P->dIds + P->off[p], F, n_fields, P->dRecv + off[p]);
+  }
+  addOwn();
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
 }

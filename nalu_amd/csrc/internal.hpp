@@ -168,6 +168,7 @@ struct nalu_gpu_linsys {
   unsigned char *dEdgeOwned = nullptr;
   // export plan (built on the first loadComplete of export mode)
   bool exportReady = false;
+  bool exportedSinceZero = false;  // loadComplete has exported the shared rows since the last zeroSystem
   std::vector<int64_t> expSendOff, expRecvOff;  // per neighbour, in doubles (value messages)
   std::vector<int> expSendRows, expRecvRows;    // rows per neighbour
   std::vector<int> expSendW, expRecvW;          // message width (entries per row) per neighbour
@@ -265,9 +266,11 @@ struct nalu_gpu_linsys {
   // dataflow SGS sweeps (precond.hip, sgs_flow.hpp): one launch per sweep, chunks of rows wait
   // for each other through the exchange buffers (data-as-flag: all-ones NaN = "not computed yet")
   int flowState = 0;  // 0 not built, 1 ready, -1 not available for this matrix (level launches instead)
+  bool flowGaveUp = false;  // a sweep gave up waiting in some solve: level launches from then on
   struct FlowDir {
     void *dChunks = nullptr;  // nalu_gpu::FlowChunk[nChunks], processing order
     int *dRowOf = nullptr, *dPubOf = nullptr, *dCode = nullptr, *dSteps = nullptr;
+    unsigned long long *dTicket = nullptr;  // chunks drawn so far (k_flow_sweep: the chunk of a workgroup is its ticket)
     double *dXch = nullptr;  // exchange buffer: the rows other chunks read, in schedule order (nVisible)
     int nVisible = 0;
     long long *dSrc = nullptr;  // SELL position of every entry's value (-1: pad)
@@ -438,6 +441,7 @@ int halo_exchange(nalu_gpu_linsys *h, double *vec);
 int halo_begin(nalu_gpu_linsys *h, const double *vec);
 int halo_end(nalu_gpu_linsys *h, double *vec);
 int export_shared_rows(nalu_gpu_linsys *h);
+int agree_counts(nalu_gpu_linsys *h, int n, long long *vals);
 // reductions: kernels leave per-block partials in dPartials[slot][block]; this sums them
 // in a fixed order into dReduce[0..nslots) and (if a comm is set) all-reduces them.
 int finish_reduction(nalu_gpu_linsys *h, int nslots, int nblocks, const double *src = nullptr);
@@ -445,6 +449,7 @@ int vec_grid(int64_t n);
 void release_plan(nalu_gpu_scatter_plan *p);
 int ensure_sgs_levels(nalu_gpu_linsys *h);
 int sgs_prepare(nalu_gpu_linsys *h);  // whichever schedule NG_SGS_MODE selects
+void sgs_flow_disable(nalu_gpu_linsys *h);
 int apply_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone);
 int sgs_compute(nalu_gpu_linsys *h);
 int ensure_mc_colors(nalu_gpu_linsys *h);

@@ -196,6 +196,8 @@ struct FlowView {
   int ringMask;  // LDS ring of in-chunk values: ring - 1, ring >= largest lookback + 64
   int maxSteps;  // most steps of any chunk (the step offsets of a chunk are copied to LDS)
   int nVisible;  // slots of the exchange buffer
+  int maxPoll;   // polls of one value before a wave gives up (FLOW_MAX_POLL; NG_SGS_MAX_POLL: the tests' way to provoke it)
+  unsigned long long *ticket;  // chunks handed out so far, over all launches of this sweep direction
   long long *trace;  // development aid (NG_SGS_TRACE): per chunk, clock at start / after the first step / at the end
 };
 
@@ -216,7 +218,7 @@ struct FlowCfg {
   }
 };
 
-__device__ __forceinline__ double flow_poll(const double *p, int *err)
+__device__ __forceinline__ double flow_poll(const double *p, int *err, int maxPoll)
 {
   unsigned long long bits;
   int spins = 0;
@@ -225,7 +227,7 @@ __device__ __forceinline__ double flow_poll(const double *p, int *err)
     if (bits != FLOW_SENT) break;
     ++spins;
     if ((spins & 15) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    if (spins >= FLOW_MAX_POLL) {
+    if (spins >= maxPoll) {
       __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
@@ -256,8 +258,16 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
   using Cfg = FlowCfg<D, W, GB>;
   constexpr int NSR = Cfg::NSR, NG = Cfg::NG, GROUP = Cfg::GROUP, WQ = W / 4;
   static_assert(W % 4 == 0 && D % 2 == 0, "ring slots are packed four to a word; two stages alternate");
-  if (done && *done) return;
   extern __shared__ double flowLds[];
+  // The chunk of this workgroup: the next one of the schedule's order at the moment the workgroup
+  // STARTS (a ticket drawn from a counter that every workgroup of every launch draws from exactly
+  // once), not blockIdx: a workgroup only ever waits for chunks earlier in that order, and those were
+  // drawn by workgroups that are running or finished, whatever order the hardware dispatches in.
+  __shared__ int sChunk;
+  if (threadIdx.x == 0) sChunk = (int)(atomicAdd(F.ticket, 1ULL) % (unsigned long long)gridDim.x);
+  __syncthreads();
+  const int chunkId = sChunk;
+  if (done && *done) return;
   const int ring = F.ringMask + 1;
   double *tring = flowLds;             // [ring] values of the chunk's last rows, [ring] = 0.0, then [NSR][2]: the
                                        // values of other chunks a staged row needs (put there by the consumer at
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
   int *abortFlag = consumed + 1;
   int *published = abortFlag + 1;      // rows the publisher has stored: their staging rows and ring slots are free
   int *sSteps = abortFlag + 3;         // [nSteps + 1]: first row of every step
-  const FlowChunk C = F.chunks[blockIdx.x];
+  const FlowChunk C = F.chunks[chunkId];
   if (threadIdx.x < NG + 4) ready[threadIdx.x] = 0;
   if (threadIdx.x < 2) tring[ring + threadIdx.x] = 0.0;
   for (int i = threadIdx.x; i <= C.nSteps; i += blockDim.x) sSteps[i] = F.steps[C.stepOff + i];
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
 
   // rows without an entry of another chunk ask for this slot instead (any valid address; one per
   // chunk, or every workgroup would hit the same memory channel twice per step)
-  const int dummyRow = F.nVisible ? (int)(blockIdx.x % (unsigned)F.nVisible) : 0;
+  const int dummyRow = F.nVisible ? (int)((unsigned)chunkId % (unsigned)F.nVisible) : 0;
 
   if (wave == 1) {  // ---- publisher: the computed values out of the LDS ring to memory
     // (the consumer itself issues no store: vector-memory operations retire in order, and a wait for
@@ -313,10 +323,14 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
           const double v = tring[q & F.ringMask];
           const int pub = sPub[q & (NSR - 1)];
           out[sRow[q & (NSR - 1)]] = v;  // (only needed after the sweep)
-          // rows that other chunks read are published at once
-          if (pub >= 0)
-            __hip_atomic_store((unsigned long long *)(xch + pub), (unsigned long long)__double_as_longlong(v),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // rows that other chunks read are published at once.  A computed value whose bits happen to be
+          // the "not computed yet" pattern (an all-ones NaN, e.g. from a 0xFF-filled rhs) goes out as
+          // another NaN: a genuine NaN must propagate, not stall the chunks that wait for this slot.
+          if (pub >= 0) {
+            unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+            if (bits == FLOW_SENT) bits = 0x7FF8000000000000ULL;
+            __hip_atomic_store((unsigned long long *)(xch + pub), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
       pub = have;
@@ -521,7 +535,7 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
         for (int k = 0; k < w; ++k) {
           const int c = F.code[(size_t)(C.entOff + (long long)k * m + S.q)];
           if (c == FLOW_PAD) break;
-          const double v = c > 0 ? tring[(S.q - c) & F.ringMask] : flow_poll(xch + ~c, err);
+          const double v = c > 0 ? tring[(S.q - c) & F.ringMask] : flow_poll(xch + ~c, err, F.maxPoll);
           const double a = sA[k * NSR + slot];
           acc = FWD ? acc - a * v : acc + a * v;
         }
@@ -539,7 +553,7 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
     while (__builtin_amdgcn_ballot_w64(refetch_missing()) != 0) {
       ++spins;
       if ((spins & 15) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-      if (spins >= FLOW_MAX_POLL) break;  // (the rows' own polls report the failure)
+      if (spins >= F.maxPoll) break;  // (the rows' own polls report the failure)
       if (spins >= 16) __builtin_amdgcn_s_sleep(32);
       else if (spins >= 4) __builtin_amdgcn_s_sleep(8);
     }
@@ -572,7 +586,7 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
 
   double ex0[D], ex1[D];
   Stage st[2];
-  if (F.trace && lane == 0) F.trace[8 * blockIdx.x] = wall_clock64();
+  if (F.trace && lane == 0) F.trace[8 * chunkId] = wall_clock64();
 #pragma unroll
   for (int j = 0; j < D; ++j) prefetch(j, ex0[j], ex1[j]);
   load_stage(0, st[0]);
@@ -603,15 +617,15 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
         __hip_atomic_store(consumed, st[j & 1].end, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       prefetch(s + D, ex0[j], ex1[j]);
     }
-    if (F.trace && lane == 0 && sb == 0) F.trace[8 * blockIdx.x + 1] = wall_clock64();
-    if (F.trace && lane == 0 && sb <= nSteps / 2) F.trace[8 * blockIdx.x + 2] = wall_clock64();
+    if (F.trace && lane == 0 && sb == 0) F.trace[8 * chunkId + 1] = wall_clock64();
+    if (F.trace && lane == 0 && sb <= nSteps / 2) F.trace[8 * chunkId + 2] = wall_clock64();
   }
   if (F.trace && lane == 0) {
-    F.trace[8 * blockIdx.x + 3] = wall_clock64();
-    F.trace[8 * blockIdx.x + 4] = trPollTicks;
-    F.trace[8 * blockIdx.x + 5] = trPolls;
-    F.trace[8 * blockIdx.x + 6] = trEnsureTicks;
-    F.trace[8 * blockIdx.x + 7] = trRingTicks;
+    F.trace[8 * chunkId + 3] = wall_clock64();
+    F.trace[8 * chunkId + 4] = trPollTicks;
+    F.trace[8 * chunkId + 5] = trPolls;
+    F.trace[8 * chunkId + 6] = trEnsureTicks;
+    F.trace[8 * chunkId + 7] = trRingTicks;
   }
 }
 
@@ -776,6 +790,9 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *o
   F.maxSteps = fd.maxSteps;
   F.pubOf = fd.dPubOf;
   F.nVisible = fd.nVisible;
+  // (read per launch: the tests shrink the bound to provoke a give-up)
+  F.maxPoll = getenv("NG_SGS_MAX_POLL") ? std::max(1, atoi(getenv("NG_SGS_MAX_POLL"))) : FLOW_MAX_POLL;
+  F.ticket = fd.dTicket;
   // the exchange buffer starts as "nothing computed yet"
   NG_HIP(hipMemsetAsync(fd.dXch, 0xFF, sizeof(double) * (size_t)std::max(fd.nVisible, 1), h->stream));
   F.trace = nullptr;
@@ -893,6 +910,8 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     NG_TRY(flow_upload(s.pubOf, &fd.dPubOf));
     fd.nVisible = s.nVisible;
     NG_HIP(hipMalloc(&fd.dXch, sizeof(double) * (size_t)std::max(s.nVisible, 1)));
+    NG_HIP(hipMalloc(&fd.dTicket, sizeof(unsigned long long)));
+    NG_HIP(hipMemset(fd.dTicket, 0, sizeof(unsigned long long)));
     NG_TRY(flow_upload(s.code, &fd.dCode));
     NG_TRY(flow_upload(s.steps, &fd.dSteps));
     NG_TRY(flow_upload(s.src, &fd.dSrc));
@@ -914,6 +933,13 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
 
 bool flow_active(const nalu_gpu_linsys *h) { return sgs_mode() == SGS_FLOW && h->flowState == 1; }
 }  // namespace
+
+// a dataflow sweep gave up (nalu_gpu_solve): this handle uses the level schedule from now on
+void nalu_gpu::sgs_flow_disable(nalu_gpu_linsys *h)
+{
+  h->flowState = -1;
+  h->flowGaveUp = true;
+}
 
 int nalu_gpu::sgs_prepare(nalu_gpu_linsys *h)
 {
@@ -1061,7 +1087,7 @@ extern "C" int nalu_gpu_get_sgs_schedule(nalu_gpu_linsys *h, int out[8])
 {
   NG_REQUIRE(h && out, NALU_GPU_EINVAL, "null argument");
   const bool flow = h->flowState == 1 && sgs_mode() == SGS_FLOW;
-  out[0] = flow ? 1 : (h->flowState != 0 || h->sgsReady) ? -1 : 0;
+  out[0] = flow ? 1 : h->flowGaveUp ? -2 : (h->flowState != 0 || h->sgsReady) ? -1 : 0;
   out[1] = flow && h->flowTiled;
   out[2] = flow ? h->flow[0].nChunks : 0;
   out[3] = flow ? std::max(h->flow[0].maxSteps, h->flow[1].maxSteps) : 0;

@@ -96,15 +96,22 @@ extern "C" int nalu_gpu_rccl_world_destroy(nalu_gpu_rccl_world *w)
 
 extern "C" int nalu_gpu_rccl_attach(nalu_gpu_rccl_world *w, nalu_gpu_linsys *h, nalu_gpu_rccl_comm **out)
 {
+  return nalu_gpu_rccl_attach_flags(w, h, 0, out);
+}
+
+extern "C" int nalu_gpu_rccl_attach_flags(nalu_gpu_rccl_world *w, nalu_gpu_linsys *h, int flags,
+                                          nalu_gpu_rccl_comm **out)
+{
   if (!w || !h || !out) return fail(NALU_GPU_EINVAL, "null argument");
+  const bool selfOk = (flags & NALU_GPU_RCCL_ALLOW_SELF_NEIGHBOUR) != 0;
   int nNbr = 0;
   const int *ranks = nullptr, *so = nullptr, *ro = nullptr;
   if (nalu_gpu_get_halo_plan(h, &nNbr, &ranks, &so, &ro) != NALU_GPU_OK)
     return fail(NALU_GPU_ESTATE, "%s", nalu_gpu_last_error());
   for (int p = 0; p < nNbr; ++p)
-    if (ranks[p] < 0 || ranks[p] >= w->nRanks || ranks[p] == w->rank)
-      return fail(NALU_GPU_EINVAL, "halo neighbour %d is rank %d: not another rank of this world of %d", p,
-                  ranks[p], w->nRanks);
+    if (ranks[p] < 0 || ranks[p] >= w->nRanks || (ranks[p] == w->rank && !selfOk))
+      return fail(NALU_GPU_EINVAL, "halo neighbour %d is rank %d: not another rank of this world of %d "
+                  "(NALU_GPU_RCCL_ALLOW_SELF_NEIGHBOUR admits the rank itself)", p, ranks[p], w->nRanks);
   DeviceScope scope(w->device);
   nalu_gpu_rccl_comm *c = new nalu_gpu_rccl_comm();
   c->h = h;

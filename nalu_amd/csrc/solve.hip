@@ -1705,31 +1705,35 @@ extern "C" int nalu_gpu_set_debug(nalu_gpu_linsys *h, int enabled)
   return NALU_GPU_OK;
 }
 
-extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, double *x_out_dev,
-                              nalu_gpu_solve_info *info, double *history, int history_cap)
+// one pass of the solve; *flowGaveUp: some rank's dataflow SGS sweep gave up waiting (the result is
+// then worthless and nothing has been written to the caller's arrays)
+static int solve_once(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, double *x_out_dev,
+                      nalu_gpu_solve_info *info, double *history, int history_cap, bool *flowGaveUp)
 {
-  NG_FINALIZED(h);
-  NG_REQUIRE(cfg && info, NALU_GPU_EINVAL, "null config/info");
-  NG_REQUIRE(cfg->method == NALU_GPU_METHOD_CG || cfg->method == NALU_GPU_METHOD_GMRES ||
-                 cfg->method == NALU_GPU_METHOD_BICGSTAB || cfg->method == NALU_GPU_METHOD_TFQMR,
-             NALU_GPU_EUNSUPPORTED, "solver method %d (supported: cg, gmres, biCgStab, tfqmr)", cfg->method);
-  NG_REQUIRE(cfg->precond == NALU_GPU_PRECOND_NONE || cfg->precond == NALU_GPU_PRECOND_JACOBI ||
-                 cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV ||
-                 cfg->precond == NALU_GPU_PRECOND_MT_SGS,
-             NALU_GPU_EUNSUPPORTED,
-             "preconditioner %d (supported: none, jacobi, sgs, mt_sgs, chebyshev; the reference throws on unknown "
-             "names, src/LinearSolverConfig.C:97-99)", cfg->precond);
-  NG_REQUIRE(cfg->max_iterations >= 0 && cfg->tolerance >= 0.0, NALU_GPU_EINVAL, "bad solver limits");
+  *flowGaveUp = false;
   NG_TRY(materialize_zero(h));
   if (h->debug) {  // realm_.debug() (src/TpetraLinearSystem.C:1716-1721)
     nalu_gpu_check_info ci;
     NG_TRY(nalu_gpu_check_system(h, &ci));
-    NG_REQUIRE(ci.lhs_nan_rows == 0 && ci.rhs_nan_rows == 0, NALU_GPU_EINVAL,
-               "bad %s: NaN in local row %lld (checkForNaN, src/TpetraLinearSystem.C:1782-1810)",
-               ci.lhs_nan_rows ? "LHS" : "RHS", (long long)(ci.lhs_nan_rows ? ci.first_lhs_nan_row : ci.first_rhs_nan_row));
-    NG_REQUIRE(ci.zero_rows == 0, NALU_GPU_EINVAL,
-               "ERROR checkForZeroRow in solve(): %lld row(s) with sum |a_ij| < 1e-10, first local row %lld",
-               (long long)ci.zero_rows, (long long)ci.first_zero_row);
+    // the solve is collective: every rank learns what any rank found, and all leave together
+    long long tot[3] = {ci.lhs_nan_rows, ci.rhs_nan_rows, ci.zero_rows};
+    NG_TRY(agree_counts(h, 3, tot));
+    if (tot[0] || tot[1]) {
+      if (ci.lhs_nan_rows || ci.rhs_nan_rows)
+        return set_error(NALU_GPU_EINVAL, "bad %s: NaN in local row %lld (checkForNaN, src/TpetraLinearSystem.C:1782-1810)",
+                         ci.lhs_nan_rows ? "LHS" : "RHS",
+                         (long long)(ci.lhs_nan_rows ? ci.first_lhs_nan_row : ci.first_rhs_nan_row));
+      return set_error(NALU_GPU_EINVAL, "bad %s: NaN in %lld row(s) of another rank (checkForNaN, "
+                       "src/TpetraLinearSystem.C:1782-1810)", tot[0] ? "LHS" : "RHS", tot[0] ? tot[0] : tot[1]);
+    }
+    if (tot[2]) {
+      if (ci.zero_rows)
+        return set_error(NALU_GPU_EINVAL,
+                         "ERROR checkForZeroRow in solve(): %lld row(s) with sum |a_ij| < 1e-10, first local row %lld",
+                         (long long)ci.zero_rows, (long long)ci.first_zero_row);
+      return set_error(NALU_GPU_EINVAL, "ERROR checkForZeroRow in solve(): %lld row(s) with sum |a_ij| < 1e-10 on "
+                       "another rank", tot[2]);
+    }
   }
   const int checkEvery = cfg->check_every > 0 ? cfg->check_every : 10;
   NG_TRY(ensure_hist(h, cfg->max_iterations + 2));
@@ -1754,15 +1758,21 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
     int *bad = (int *)((char *)h->hPinned + 3072);
     NG_HIP(hipMemcpyAsync(bad, dBad, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     NG_HIP(hipStreamSynchronize(h->stream));
-    // every rank must leave together (the solve is collective): the verdict is all-reduced below
-    // only when a comm is set; a lone rank just reports
-    if (bad[0] > 0 && !h->hasComm) {
-      const int row = h->nOwned - bad[1];
+    // every rank must leave together (the solve is collective): the count is summed over the ranks
+    // before anyone decides
+    const int nBad = bad[0], firstBad = h->nOwned - bad[1];
+    long long tot[1] = {nBad};
+    NG_TRY(agree_counts(h, 1, tot));
+    if (tot[0] > 0) {
+      if (nBad > 0)
+        return set_error(NALU_GPU_EINVAL,
+                         "%d row(s) have a zero, missing or non-finite diagonal (first: local row %d, global id "
+                         "%lld): the %s preconditioner cannot be built (Ifpack2 would produce inf; "
+                         "checkForZeroRow, src/TpetraLinearSystem.C:1716-1721, catches it in debug runs)",
+                         nBad, firstBad, (long long)h->gids[firstBad], "relaxation");
       return set_error(NALU_GPU_EINVAL,
-                       "%d row(s) have a zero, missing or non-finite diagonal (first: local row %d, global id "
-                       "%lld): the %s preconditioner cannot be built (Ifpack2 would produce inf; "
-                       "checkForZeroRow, src/TpetraLinearSystem.C:1716-1721, catches it in debug runs)",
-                       bad[0], row, (long long)h->gids[row], "relaxation");
+                       "%lld row(s) on other ranks have a zero, missing or non-finite diagonal: the relaxation "
+                       "preconditioner cannot be built (every rank leaves the solve together)", tot[0]);
     }
   }
   const auto t1 = std::chrono::steady_clock::now();
@@ -1792,9 +1802,14 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
   NG_HIP(hipMemcpyAsync(flowErr, dBad + 2, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   SolverScalars sc;
   NG_TRY(read_scalars(h, &sc));
-  NG_REQUIRE(*flowErr == 0, NALU_GPU_ESTATE,
-             "sgs: a dataflow sweep gave up waiting for rows of another chunk (workgroups not dispatched in order, "
-             "or an all-ones NaN in the residual); NG_SGS_MODE=levels selects the sweeps with one launch per level");
+  {  // a sweep that gave up on any rank voids the solve on all of them (SGS is rank-local, the solve is not)
+    long long gaveUp[1] = {*flowErr != 0};
+    NG_TRY(agree_counts(h, 1, gaveUp));
+    if (gaveUp[0]) {
+      *flowGaveUp = true;
+      return NALU_GPU_OK;
+    }
+  }
   const auto t2 = std::chrono::steady_clock::now();
   info->iters = sc.iter;
   info->final_resid = std::sqrt(pin[0]);
@@ -1810,5 +1825,34 @@ extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *
   if (x_out_dev)
     NG_HIP(hipMemcpyAsync(x_out_dev, h->dX, sizeof(double) * (size_t)h->nCols, hipMemcpyDeviceToDevice, h->stream));
   NG_HIP(hipStreamSynchronize(h->stream));
+  return NALU_GPU_OK;
+}
+
+extern "C" int nalu_gpu_solve(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, double *x_out_dev,
+                              nalu_gpu_solve_info *info, double *history, int history_cap)
+{
+  NG_FINALIZED(h);
+  NG_REQUIRE(cfg && info, NALU_GPU_EINVAL, "null config/info");
+  NG_REQUIRE(cfg->method == NALU_GPU_METHOD_CG || cfg->method == NALU_GPU_METHOD_GMRES ||
+                 cfg->method == NALU_GPU_METHOD_BICGSTAB || cfg->method == NALU_GPU_METHOD_TFQMR,
+             NALU_GPU_EUNSUPPORTED, "solver method %d (supported: cg, gmres, biCgStab, tfqmr)", cfg->method);
+  NG_REQUIRE(cfg->precond == NALU_GPU_PRECOND_NONE || cfg->precond == NALU_GPU_PRECOND_JACOBI ||
+                 cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV ||
+                 cfg->precond == NALU_GPU_PRECOND_MT_SGS,
+             NALU_GPU_EUNSUPPORTED,
+             "preconditioner %d (supported: none, jacobi, sgs, mt_sgs, chebyshev; the reference throws on unknown "
+             "names, src/LinearSolverConfig.C:97-99)", cfg->precond);
+  NG_REQUIRE(cfg->max_iterations >= 0 && cfg->tolerance >= 0.0, NALU_GPU_EINVAL, "bad solver limits");
+  bool gaveUp = false;
+  NG_TRY(solve_once(h, cfg, x_out_dev, info, history, history_cap, &gaveUp));
+  if (gaveUp) {
+    // A dataflow SGS sweep gave up waiting for rows of another chunk (a workgroup that never got its
+    // turn).  The schedule with one launch per level computes the same sweeps bit for bit and waits
+    // for nothing: this solve is redone on it, from scratch, and so is every later one on this handle
+    // (nalu_gpu_get_sgs_schedule reports -2).
+    sgs_flow_disable(h);
+    NG_TRY(solve_once(h, cfg, x_out_dev, info, history, history_cap, &gaveUp));
+    NG_REQUIRE(!gaveUp, NALU_GPU_ESTATE, "sgs: internal error, the level schedule reported a dataflow failure");
+  }
   return NALU_GPU_OK;
 }

@@ -93,6 +93,28 @@ class ScatterPlan:
             pass
 
 
+class SharePlan:
+    """nalu_gpu_share_plan: the shared entities of every halo neighbour (stk::mesh::parallel_sum)."""
+
+    def __init__(self, owner, offsets, local_ids, n_entities):
+        off, ids = _np(offsets, np.int32), _np(local_ids, np.int32)
+        self.owner, self.n_entities = owner, int(n_entities)
+        self.p = C.c_void_p()
+        L.check(owner.lib.nalu_gpu_share_plan_create(owner.h, off.ctypes.data, ids.ctypes.data, self.n_entities,
+                                                     C.byref(self.p)))
+
+    def close(self):
+        if self.p and self.owner.h:  # (before its linear system goes away)
+            self.owner.lib.nalu_gpu_share_plan_destroy(self.p)
+        self.p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def suggest_edge_order(edge_nodes):
     """nalu_gpu_suggest_edge_order: the slot-major permutation (perm[new] = old) of an edge list of local
     node ids -- apply it to the edge list AND to every edge field before buildEdgeToNodeGraph."""
@@ -457,6 +479,29 @@ class GpuLinearSystem:
             self.h, n, dt, gamma1, _vec3(dpdx_new), _vec3(dpdx_old), _ptr(density),
             _ptr(projected), _vec3(velocity)))
 
+    def update_and_clip(self, dz, z, z_unfiltered=None, delta_clip=0.0, diagnostics=False):
+        """z += dz, clipped to [0 - delta_clip, 1 + delta_clip] (src/MixtureFractionEquationSystem.C:942-1013);
+        diagnostics: returns [n_clipped_low, n_clipped_high, min, max] of this rank"""
+        n = z.numel()
+        assert dz.numel() >= n and z.is_contiguous() and dz.is_contiguous() and z.element_size() == 8
+        assert z_unfiltered is None or (z_unfiltered.numel() >= n and z_unfiltered.is_contiguous())
+        info = np.zeros(4) if diagnostics else None
+        L.check(self.lib.nalu_gpu_update_and_clip(self.h, n, _ptr(dz), _ptr(z), _ptr(z_unfiltered), delta_clip,
+                                                  None if info is None else info.ctypes.data))
+        return info
+
+    def createSharePlan(self, offsets, local_ids, n_entities):
+        """share plan of stk::mesh::parallel_sum: per halo neighbour the local indices of the shared entities"""
+        return SharePlan(self, offsets, local_ids, n_entities)
+
+    def parallel_sum(self, plan, fields):
+        """stk::mesh::parallel_sum of device arrays (each indexed by the plan's entity index)"""
+        assert plan.owner is self and 1 <= len(fields) <= 16
+        for t in fields:
+            assert t.dim() == 1 and t.is_contiguous() and t.element_size() == 8 and t.numel() >= plan.n_entities
+        ptrs = (C.c_void_p * len(fields))(*[t.data_ptr() for t in fields])
+        L.check(self.lib.nalu_gpu_parallel_sum(self.h, plan.p, len(fields), ptrs))
+
     def set_halo_plan(self, neighbor_ranks, send_offsets, send_lids, recv_offsets, recv_lids=None):
         nb = _np(neighbor_ranks, np.int32)
         so, sl, ro = _np(send_offsets, np.int32), _np(send_lids, np.int32), _np(recv_offsets, np.int32)
@@ -492,8 +537,8 @@ class GpuLinearSystem:
         """how the exact SGS sweeps run (nalu_gpu_get_sgs_schedule): dict with mode 'flow' / 'levels' / None"""
         out = (C.c_int * 8)()
         L.check(self.lib.nalu_gpu_get_sgs_schedule(self.h, out))
-        mode = {1: "flow", -1: "levels", 0: None}[out[0]]
-        return dict(mode=mode, tiled=bool(out[1]), chunks=out[2], max_steps=out[3], widest_row=out[4],
+        mode = {1: "flow", -1: "levels", -2: "levels", 0: None}[out[0]]
+        return dict(mode=mode, fell_back=out[0] == -2, tiled=bool(out[1]), chunks=out[2], max_steps=out[3], widest_row=out[4],
                     ring=out[5], tile=(out[6], out[7]))
 
     def timer_launches(self, name):

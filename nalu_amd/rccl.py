@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 RCCL_LIB_PATH = os.environ.get("NALU_GPU_RCCL_LIB", os.path.join(_HERE, "libnalu_gpu_rccl.so"))
 ID_BYTES = 128
 SYMBOLS = ["nalu_gpu_rccl_get_unique_id", "nalu_gpu_rccl_world_create", "nalu_gpu_rccl_world_destroy",
-           "nalu_gpu_rccl_attach", "nalu_gpu_rccl_detach", "nalu_gpu_rccl_last_error"]
+           "nalu_gpu_rccl_attach", "nalu_gpu_rccl_attach_flags", "nalu_gpu_rccl_detach", "nalu_gpu_rccl_last_error"]
 _lib = None
 
 
@@ -29,6 +29,7 @@ def load():
                        "nalu_gpu_rccl_world_create": [vp, ci, ci, ci, C.POINTER(vp)],
                        "nalu_gpu_rccl_world_destroy": [vp],
                        "nalu_gpu_rccl_attach": [vp, vp, C.POINTER(vp)],
+                       "nalu_gpu_rccl_attach_flags": [vp, vp, ci, C.POINTER(vp)],
                        "nalu_gpu_rccl_detach": [vp]}.items():
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = ci
@@ -66,10 +67,12 @@ class RcclWorld:
         self.rank, self.n_ranks = rank, n_ranks
         self._comms = []
 
-    def attach(self, linsys):
-        """Install the RCCL callbacks on a finalized GpuLinearSystem whose halo plan is set."""
+    def attach(self, linsys, allow_self_neighbour=False):
+        """Install the RCCL callbacks on a finalized GpuLinearSystem whose halo plan is set.
+        allow_self_neighbour: a halo neighbour may be this rank (a mesh periodic across its own boundary;
+        the loop-back test of the one-GPU box)."""
         c = C.c_void_p()
-        _check(load().nalu_gpu_rccl_attach(self.w, linsys.h, C.byref(c)))
+        _check(load().nalu_gpu_rccl_attach_flags(self.w, linsys.h, 1 if allow_self_neighbour else 0, C.byref(c)))
         self._comms.append(c)
         return c
 

@@ -1029,6 +1029,34 @@ void orc_project_nodal_velocity(int64_t nnodes, double dt, double gamma1, const 
   }
 }
 
+/* src/MixtureFractionEquationSystem.C:942-1013 (update_and_clip): z += zTmp, the un-filtered value
+ * kept in zUF, z clipped to [0 - deltaZ, 1 + deltaZ]; info = {numClip[0], numClip[1], minZ, maxZ} of
+ * this rank (the all_reduce of :993-1006 is the caller's) */
+void orc_update_and_clip(int64_t nnodes, const double *zTmp, double *mixFrac, double *mixFracUF,
+                         double deltaZ, double *info)
+{
+  const double lowBound = 0.0 - deltaZ;
+  const double highBound = 1.0 + deltaZ;
+  double numClip[2] = {0.0, 0.0};
+  double minZ = +1.0e16;
+  double maxZ = -1.0e16;
+  for (int64_t k = 0; k < nnodes; ++k) {
+    double mixFracNp1 = mixFrac[k] + zTmp[k];
+    if (mixFracUF) mixFracUF[k] = mixFracNp1;
+    if (mixFracNp1 < lowBound) {
+      minZ = mixFracNp1 < minZ ? mixFracNp1 : minZ;
+      mixFracNp1 = lowBound;
+      numClip[0] += 1.0;
+    } else if (mixFracNp1 > highBound) {
+      maxZ = mixFracNp1 > maxZ ? mixFracNp1 : maxZ;
+      mixFracNp1 = highBound;
+      numClip[1] += 1.0;
+    }
+    mixFrac[k] = mixFracNp1;
+  }
+  if (info) { info[0] = numClip[0]; info[1] = numClip[1]; info[2] = minZ; info[3] = maxZ; }
+}
+
 /* =============================================================== solver */
 
 void orc_spmv(const orc_linsys *ls, const double *x, double *y)

@@ -172,6 +172,8 @@ void orc_field_axpby(int64_t n, double alpha, const double *x, double beta, doub
 void orc_project_nodal_velocity(int64_t nnodes, double dt, double gamma1, const double *dpdx_new,
                                 const double *dpdx_old, const double *density,
                                 const unsigned char *projected, double *velocity);
+void orc_update_and_clip(int64_t nnodes, const double *zTmp, double *mixFrac, double *mixFracUF,
+                         double deltaZ, double *info);
 
 /* -------------------------------------------------------------- solver */
 /* y = A x on the owned CSR (Tpetra CrsMatrix::apply call site src/LinearSolver.C:164) */

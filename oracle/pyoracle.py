@@ -116,6 +116,7 @@ def _bind(lib):
     lib.orc_field_axpby.argtypes = [C.c_int64, C.c_double, _dp, C.c_double, _dp]
     lib.orc_project_nodal_velocity.argtypes = [C.c_int64, C.c_double, C.c_double, _dp, _dp, _dp,
                                                C.c_void_p, _dp]
+    lib.orc_update_and_clip.argtypes = [C.c_int64, _dp, _dp, _dp, C.c_double, _dp]
     lib.orc_spmv.argtypes = [C.POINTER(_LinSys), _dp, _dp]
     lib.orc_solve.argtypes = [C.POINTER(_LinSys), C.POINTER(SolverConfig), C.POINTER(C.c_double),
                               _dp, C.c_int, C.POINTER(C.c_int)]
@@ -355,6 +356,13 @@ def project_nodal_velocity(dt, gamma1, dpdx_new, dpdx_old, rho, vel, projected=N
     lib().orc_project_nodal_velocity(len(rho), dt, gamma1, f64(dpdx_new), f64(dpdx_old), f64(rho),
                                      None if m is None else m.ctypes.data, u)
     return u
+
+
+def update_and_clip(z, dz, delta_clip=0.0):
+    """returns (z_new, z_unfiltered, [n_clip_low, n_clip_high, min, max])"""
+    zn, uf, info = f64(z).copy(), np.zeros(len(z)), np.zeros(4)
+    lib().orc_update_and_clip(len(zn), f64(dz), zn, uf, delta_clip, info)
+    return zn, uf, info
 
 
 def set_values(ls, vals):

@@ -368,6 +368,309 @@ def export_test(rank, world):
         g.close()
 
 
+def baddiag_test(rank, world):
+    """a zero diagonal (or, in debug mode, a zero row / NaN) on ONE rank must end the
+    collective solve on EVERY rank with the same error code -- not leave the healthy ranks inside the
+    next all-reduce for good, and not run the solve on inf / NaN."""
+    from oracle import pyoracle as po
+    from common import Case
+    from nalu_amd.comm import TorchComm
+    from nalu_amd._lib import NaluGpuError
+    dims = (7, 6, 15)
+    c = Case(po, 0, 0.125, dims=dims)
+    S = nalu_amd.BoxSlab(*dims, rank, world)
+    gi = S.gids - 1
+    key = c.m.edge_nodes[:, 0].astype(np.int64) * c.m.nnodes + c.m.edge_nodes[:, 1]
+    ge = np.searchsorted(key, gi[S.edge_nodes[:, 0]] * c.m.nnodes + gi[S.edge_nodes[:, 1]])
+    dev = "cuda:0"
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    g = nalu_amd.GpuLinearSystem(1, 0, torch.cuda.current_stream().cuda_stream)
+    g.beginLinearSystemConstruction(S.n_owned, S.n_shared, S.n_ghost, S.gids, S.owners, rank)
+    g.buildEdgeToNodeGraph(S.edge_nodes)
+    g.finalizeLinearSystem()
+    g.set_halo_plan(S.neighbors, S.send_offsets, S.send_lids, S.recv_offsets)
+    comm = TorchComm(g, S.neighbors, S.send_offsets, S.recv_offsets, dev)
+
+    def assemble(bad):
+        g.zeroSystem()
+        g.assemble_continuity_edges(t(c.m.xyz[gi].T), t(c.dpdx[gi].T), t(c.vel[gi].T), t(c.p[gi]), t(c.rho[gi]),
+                                    t(c.area[ge].T), c.dt)
+        if rank == 0:
+            g.resetRows([0])
+            g.sumInto([0], [0.0 - c.p[0]], [1.0])
+        if bad == "zero_row" and rank == world - 1:
+            g.resetRows([5])  # the whole row, diagonal included
+        if bad == "nan" and rank == world - 1:
+            g.sumInto([5], [float("nan")], [0.0])
+        g.loadComplete()
+
+    cfg = nalu_amd.LinearSolverConfig(method="cg", preconditioner="jacobi", tolerance=1e-8, max_iterations=100)
+    for bad, debug, needle in (("zero_row", False, "diagonal"), ("zero_row", True, "checkForZeroRow"),
+                               ("nan", True, "NaN"), (None, True, None)):
+        assemble(bad)
+        g.set_debug(debug)
+        try:
+            g.solve(cfg)
+            err = None
+        except NaluGpuError as e:
+            err = str(e)
+        if bad is None:
+            assert err is None and g.linearSolveIterations > 0, err
+        else:
+            # every rank: error code 1 (NALU_GPU_EINVAL); the rank at fault names its row, the others say whose
+            assert err is not None and "nalu_gpu error 1" in err and needle in err, (rank, bad, debug, err)
+            assert ("local row" in err) == (rank == world - 1), (rank, err)
+    assert not comm.errors, comm.errors
+    it = torch.tensor([g.linearSolveIterations])
+    dist.all_reduce(it, op=dist.ReduceOp.MAX)
+    assert it.item() == g.linearSolveIterations  # the ranks are still in step
+    g.close()
+
+
+class LoopbackComm:
+    """The comm callbacks of a rank whose halo neighbours are the rank itself (a mesh periodic across its
+    own boundary): the k-th send is the k-th receive.  Plain torch copies on the library's stream --
+    the reference implementation the native RCCL loop-back is compared with."""
+
+    def __init__(self, linsys, n_nbr, send_offsets, recv_offsets, device):
+        from nalu_amd import _lib as L
+        from nalu_amd.comm import wrap_device
+        (sb, sc), (rb, rc), _ = linsys.comm_buffers()
+        self.send, self.recv = wrap_device(sb, sc, device), wrap_device(rb, rc, device)
+        self.so, self.ro, self.n, self.device = list(send_offsets), list(recv_offsets), n_nbr, device
+        self.calls = dict(allreduce=0, begin=0, end=0, rows=0)
+        self.errors = []
+        self._wrap = wrap_device
+
+        def on(stream):
+            return torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=device) if stream
+                                     else torch.cuda.default_stream(device))
+
+        def allreduce(ctx, count, stream):
+            self.calls["allreduce"] += 1
+            return 0  # one rank: the sum is the value
+
+        def begin(ctx, stream):
+            self.calls["begin"] += 1
+            return 0
+
+        def end(ctx, stream):
+            try:
+                self.calls["end"] += 1
+                with on(stream):
+                    for p in range(self.n):
+                        self.recv[self.ro[p]:self.ro[p + 1]].copy_(self.send[self.so[p]:self.so[p + 1]])
+                return 0
+            except Exception as e:  # pragma: no cover
+                self.errors.append(repr(e))
+                return 1
+
+        def rows(ctx, send_ptr, send_off, recv_ptr, recv_off, stream):
+            try:
+                self.calls["rows"] += 1
+                so = [int(send_off[p]) for p in range(self.n + 1)]
+                ro = [int(recv_off[p]) for p in range(self.n + 1)]
+                snd, rcv = self._wrap(send_ptr, so[-1], device), self._wrap(recv_ptr, ro[-1], device)
+                with on(stream):
+                    for p in range(self.n):
+                        assert so[p + 1] - so[p] == ro[p + 1] - ro[p]
+                        if ro[p + 1] > ro[p]:
+                            rcv[ro[p]:ro[p + 1]].copy_(snd[so[p]:so[p + 1]])
+                return 0
+            except Exception as e:  # pragma: no cover
+                self.errors.append(repr(e))
+                return 1
+
+        self._cb = (L.ALLREDUCE_FN(allreduce), L.EXCHANGE_FN(begin), L.EXCHANGE_FN(end), L.EXCHANGE_ROWS_FN(rows))
+        self.struct = L.Comm(None, *self._cb)
+        linsys.set_comm(self.struct)
+
+
+def loopback_test(rank, world):
+    """the grouped ncclSend / ncclRecv of the native RCCL callbacks, their side
+    stream and event hand-over, spmv_with_halo's interior / boundary split and exchange_rows REALLY
+    run on RCCL -- on the one GPU of the test box, where RCCL admits one rank: the rank is its own
+    neighbour.  The mesh is a box that is periodic in z: the rank owns all nz planes and holds a copy
+    of its last plane below the first one (shared-not-owned) and a copy of its first plane above the
+    last one (ghost); neighbour slot 0 carries last plane -> lower copy, slot 1 first plane -> upper
+    copy, both to rank 0 itself (NALU_GPU_RCCL_ALLOW_SELF_NEIGHBOUR).
+    Checked against the ORACLE: the rows of a non-periodic box with one more plane on either side,
+    columns folded back (the periodic operator), solved by the oracle's Krylov loops; and against
+    the same solves with plain torch copies in place of RCCL (bit for bit)."""
+    assert world == 1 and rank == 0
+    from oracle import pyoracle as po
+    from common import Case, rel_err
+    from nalu_amd.box import box_edges
+    from nalu_amd.rccl import RcclWorld
+    nx, ny, nz = 9, 8, 13
+    plane, N = nx * ny, nx * ny * nz
+    c = Case(po, 0, 0.125, dims=(nx, ny, nz + 2))  # planes -1 .. nz of the periodic box
+    # local numbering: owned (ext planes 1 .. nz) | copy of the last owned plane at ext plane 0 | copy of the first at nz + 1
+    tt = np.arange((nz + 2) * plane, dtype=np.int64)
+    kk = tt // plane
+    own = (kk >= 1) & (kk <= nz)
+    lid = np.where(own, tt - plane, np.where(kk == 0, N + tt % plane, N + plane + tt % plane))
+    ext_of = np.argsort(lid)  # local id -> node of the extended box
+    gids = np.concatenate([np.arange(1, N + 1), N - plane + 1 + np.arange(plane), 1 + np.arange(plane)])
+    en, _ = box_edges(nx, ny, nz + 2)
+    en = en[own[en[:, 0]] | own[en[:, 1]]]
+    edge_nodes = np.ascontiguousarray(lid[en].astype(np.int32))
+    key = c.m.edge_nodes[:, 0].astype(np.int64) * c.m.nnodes + c.m.edge_nodes[:, 1]
+    ge = np.searchsorted(key, en[:, 0].astype(np.int64) * c.m.nnodes + en[:, 1])
+    assert np.array_equal(key[ge], en[:, 0].astype(np.int64) * c.m.nnodes + en[:, 1])
+    dev = "cuda:0"
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    nbr = [0, 0]
+    so, ro = [0, plane, 2 * plane], [0, plane, 2 * plane]
+    sl = np.concatenate([np.arange(N - plane, N), np.arange(plane)]).astype(np.int32)
+    rworld = RcclWorld(0, 1, 0)
+
+    def system(mode, comm_kind):
+        g = nalu_amd.GpuLinearSystem(1, 0, torch.cuda.current_stream().cuda_stream)
+        g.set_assembly_mode(mode)
+        g.beginLinearSystemConstruction(N, plane, plane, gids, None, 0)  # owners: all this rank
+        g.buildEdgeToNodeGraph(edge_nodes)
+        if mode == "export":
+            # every edge once: the wrap edges as (lower copy of the last plane -> first plane); their
+            # twins (last plane -> upper copy of the first plane) only shape the graph
+            L_, R_ = edge_nodes[:, 0], edge_nodes[:, 1]
+            g.set_edge_ownership(~((L_ >= N + plane) | (R_ >= N + plane)))
+        g.finalizeLinearSystem()
+        g.set_halo_plan(nbr, so, sl, ro)
+        if comm_kind == "rccl":
+            h = rworld.attach(g, allow_self_neighbour=True)
+            return g, h
+        return g, LoopbackComm(g, 2, so, ro, dev)
+
+    # truly periodic inputs (export mode assembles a wrap edge from its LOWER image, owner-computes from
+    # the upper one: the two only agree when the images carry the same data): copies = their masters,
+    # z shifted by the period; the lower wrap edges get the upper ones' area vectors
+    e = ext_of
+    master = np.concatenate([np.arange(N), N - plane + np.arange(plane), np.arange(plane)])
+    Lz = c.m.xyz[plane * nz, 2] - c.m.xyz[0, 2]  # (corner nodes are not perturbed)
+    per_f = {}
+    for name, a in (("xyz", c.m.xyz), ("dpdx", c.dpdx), ("vel", c.vel), ("p", c.p), ("rho", c.rho)):
+        per_f[name] = a[e][master].copy()
+    per_f["xyz"][N:N + plane, 2] -= Lz
+    per_f["xyz"][N + plane:, 2] += Lz
+    area_p = c.area[ge].copy()
+    Ll, Rl = edge_nodes[:, 0], edge_nodes[:, 1]
+    low = np.nonzero((Ll >= N) & (Ll < N + plane))[0]   # (lower copy of the last plane -> first plane)
+    up = np.nonzero(Rl >= N + plane)[0]                 # (last plane -> upper copy of the first plane)
+    assert len(low) == plane and len(up) == plane
+    area_p[low[np.argsort(Rl[low])]] = area_p[up[np.argsort(Ll[up])]]
+
+    def assemble(g, pin=True, periodic=False):
+        g.zeroSystem()
+        if periodic:
+            g.assemble_continuity_edges(t(per_f["xyz"].T), t(per_f["dpdx"].T), t(per_f["vel"].T), t(per_f["p"]),
+                                        t(per_f["rho"]), t(area_p.T), c.dt)
+        else:
+            g.assemble_continuity_edges(t(c.m.xyz[e].T), t(c.dpdx[e].T), t(c.vel[e].T), t(c.p[e]), t(c.rho[e]),
+                                        t(c.area[ge].T), c.dt)
+        if pin:
+            g.resetRows([0])
+            g.sumInto([0], [0.0 - c.p[e[0]]], [1.0])
+        g.loadComplete()
+
+    g, hcomm = system("owner_computes", "rccl")
+    # 1. the exchange itself: every copy gets its master's value (send k <-> receive k)
+    f = lambda gg: np.sin(0.37 * gg) + gg
+    v = torch.zeros(N + 2 * plane, dtype=torch.float64, device=dev)
+    v[:N] = t(f(gids[:N]))
+    torch.cuda.synchronize()
+    g.halo_exchange(v)
+    g.synchronize()
+    assert np.array_equal(v.cpu().numpy(), f(gids))
+    # 2. owned rows == rows of the extended box (the oracle's), column by column
+    assemble(g)
+    ls_ext = c.oracle_continuity()
+    erp, eci, ev = ls_ext.owned_csr()
+    eb = ls_ext.owned_rhs()
+    rp, ci = g.graph()
+    gv, gb = g.matrix_values(), g.rhs()
+    fold = lambda ec: np.where(ec // plane == 0, ec + (nz - 1) * plane, np.where(ec // plane == nz + 1, ec - (nz + 1) * plane, ec - plane))
+    per = po.LinSys(1, N)  # the periodic operator on the oracle: same graph through the folded edges
+    pe = np.sort(fold(en.astype(np.int64)), axis=1)
+    per.add_connections(np.unique(pe, axis=0).astype(np.int32))
+    per.finalize()
+    per.zero()
+    prp, pci, _ = per.owned_csr()
+    pv = np.zeros(len(pci))
+    for r in range(N):
+        E = ext_of[r]
+        cols_e = eci[erp[E]:erp[E + 1]]
+        vals_e = ev[erp[E]:erp[E + 1]]
+        if r == 0:  # the pinned row
+            cols_e, vals_e = np.array([E]), np.array([1.0])
+        # GPU row r through extended ids
+        cg = ext_of[ci[rp[r]:rp[r + 1]]]
+        o = np.argsort(cg)
+        if r != 0:
+            assert np.array_equal(cg[o], cols_e), r
+            assert np.abs(gv[rp[r]:rp[r + 1]][o] - vals_e).max() <= 1e-12 * np.abs(vals_e).max(), r
+        fc = fold(cols_e)
+        oo = np.argsort(fc)
+        seg = slice(prp[r], prp[r + 1])
+        if r != 0:
+            assert np.array_equal(fc[oo], pci[seg]), r
+            pv[seg] = vals_e[oo]
+        else:
+            pv[seg] = np.where(pci[seg] == 0, 1.0, 0.0)
+    pb = eb[ext_of[:N]].copy()
+    pb[0] = 0.0 - c.p[ext_of[0]]
+    assert rel_err(gb, pb) <= 1e-12
+    po.set_values(per, pv)
+    po.set_rhs(per, pb)
+    kw = dict(tolerance=1e-9, max_iterations=300, kspace=30)
+    li = g.layout_info()
+    results = {}
+    for method, pc in (("cg", "jacobi"), ("gmres", "jacobi"), ("cg", "chebyshev")):
+        ref = per.solve(method, pc, **kw)
+        x = torch.zeros(N + 2 * plane, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        g.solve(nalu_amd.LinearSolverConfig(method=method, preconditioner=pc, **kw), x)
+        assert g.linearSolveIterations == ref["iters"] and ref["iters"] > 5, (method, pc, g.linearSolveIterations, ref["iters"])
+        assert np.abs(g.history - ref["history"]).max() <= 1e-10, (method, pc)
+        xs = x.cpu().numpy()
+        assert rel_err(xs[:N], ref["x"]) <= 1e-9
+        assert np.array_equal(xs[N:N + plane], xs[N - plane:N]) and np.array_equal(xs[N + plane:], xs[:plane])
+        assert abs(g.linearResidual - ref["final_resid"]) <= 1e-10
+        results[(method, pc)] = (g.history.copy(), xs)
+    rworld.detach(hcomm)
+    g.close()
+    # 3. the same solves with torch copies instead of RCCL: bit for bit
+    g, lb = system("owner_computes", "torch")
+    assemble(g)
+    for (method, pc), (hist, xs) in results.items():
+        x = torch.zeros(N + 2 * plane, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        g.solve(nalu_amd.LinearSolverConfig(method=method, preconditioner=pc, **kw), x)
+        assert np.array_equal(g.history, hist) and np.array_equal(x.cpu().numpy(), xs), (method, pc)
+    assert not lb.errors and lb.calls["end"] > 50 and lb.calls["allreduce"] > 50, (lb.errors, lb.calls)
+    assemble(g, pin=False, periodic=True)
+    ref_v, ref_b = g.matrix_values(), g.rhs()
+    g.close()
+    # 4. export mode (exchange_rows) over RCCL and over torch copies: the wrap edges are assembled on the
+    # lower copies' rows and exported to the rows of the last plane (Tpetra Export, ADD)
+    for kind in ("rccl", "torch"):
+        g, hc = system("export", kind)
+        assemble(g, pin=False, periodic=True)
+        assert rel_err(g.matrix_values(), ref_v) <= 1e-12 and rel_err(g.rhs(), ref_b) <= 1e-12, kind
+        try:
+            g.loadComplete()
+            raise AssertionError("a second loadComplete must be refused")
+        except nalu_amd._lib.NaluGpuError as e:
+            assert "already exported" in str(e)
+        if kind == "rccl":
+            rworld.detach(hc)
+        else:
+            assert not hc.errors and hc.calls["rows"] >= 3, (hc.errors, hc.calls)
+        g.close()
+    rworld.close()
+    print("loopback: interior slices", li["n_slices"], flush=True)
+
+
 def main():
     mode = sys.argv[1]
     import datetime
@@ -384,6 +687,10 @@ def main():
         export_test(rank, world)
     elif mode == "config":
         config_test(rank, world, sys.argv[2])
+    elif mode == "baddiag":
+        baddiag_test(rank, world)
+    elif mode == "loopback":
+        loopback_test(rank, world)
     elif mode == "plan_block":
         plan_test(rank, world, block=True)
     elif mode == "block":

@@ -41,7 +41,7 @@ def test_rccl_library_exports_its_header():
     text = open(os.path.join(ROOT, "include", "nalu_gpu_rccl.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = sorted(set(re.findall(r"\b(nalu_gpu_rccl_[a-z0-9_]+)\s*\(", text)))
-    assert names == sorted(rccl.SYMBOLS) and len(names) == 6
+    assert names == sorted(rccl.SYMBOLS) and len(names) == 7
     assert os.path.exists(rccl.RCCL_LIB_PATH), "libnalu_gpu_rccl.so is missing: run __graft_entry__.build()"
     import torch  # noqa: F401  (its bundled HIP / RCCL runtime is the one the library binds to)
     lib = C.CDLL(rccl.RCCL_LIB_PATH)

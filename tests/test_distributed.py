@@ -83,6 +83,23 @@ def test_native_rccl_callbacks_world_1(method, side_stream):
 
 
 @pytest.mark.gpu
+def test_native_rccl_send_recv_loopback_on_a_periodic_box():
+    """ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the side stream, the
+    event hand-over, the interior / boundary split of the SpMV and exchange_rows all execute on RCCL
+    with ONE rank: a z-periodic box whose rank is its own neighbour.  Oracle parity (periodic operator
+    on the CPU), and bit-identity with torch copies in place of RCCL."""
+    _launch(1, "loopback", backend="nccl", timeout=240)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_an_error_on_one_rank_ends_the_solve_on_every_rank(nproc):
+    """zero diagonal / zero row / NaN on one rank -> NALU_GPU_EINVAL on all ranks,
+    no hang, and the ranks are still in step afterwards."""
+    _launch(nproc, "baddiag", timeout=240)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["strong256", "weak512", "scalar256"])
 def test_baseline_configs_3_4_5_two_ranks_on_one_gpu(kind):
     """BASELINE config 3 (256^3 Poisson split over the GPUs), the per-GPU geometry of config 5

@@ -176,3 +176,53 @@ def test_wide_rows_fall_back_to_level_sweeps(G, torch, oracle):
     assert g.sgs_schedule()["mode"] == "levels"
     ref = ls.solve("gmres", "sgs", **kw)
     assert it == ref["iters"] and np.abs(hist - ref["history"]).max() <= TOL_SOLVE
+
+
+def test_a_sweep_that_gives_up_is_redone_on_the_level_schedule(G, torch, oracle):
+    """NG_SGS_MAX_POLL=1: a consumer gives up the first time a value of another chunk is not there yet
+    (what a workgroup that never got its turn would cause after the real bound).  nalu_gpu_solve must
+    not return garbage or NALU_GPU_ESTATE: it redoes the solve on the level schedule in the same call
+    (same bits as NG_SGS_MODE=levels), reports the fall-back, and the handle stays on that schedule."""
+    m = oracle.BoxMesh(20, 20, 20)
+    kw = dict(tolerance=1e-11, max_iterations=60, kspace=30)
+    with _Env(NG_SGS_MODE=None, NG_SGS_INPLACE=None, NG_SGS_TILE="4,4", NG_SGS_CHUNK=None):
+        with _Env(NG_SGS_MODE="levels"):
+            g2, _ = _system(G, oracle, m, False, seed=3)
+            ref = {meth: _solve(G, g2, meth, **kw) for meth in ("cg", "gmres", "tfqmr")}
+        g, ls = _system(G, oracle, m, False, seed=3)
+        with _Env(NG_SGS_MAX_POLL="1"):
+            got = _solve(G, g, "cg", **kw)
+        sched = g.sgs_schedule()
+        assert sched["mode"] == "levels" and sched["fell_back"], sched
+        assert got[0] == ref["cg"][0] and np.array_equal(got[1], ref["cg"][1]) and np.array_equal(got[2], ref["cg"][2])
+        # later solves on this handle: level schedule, no second fall-back needed
+        for meth in ("gmres", "tfqmr"):
+            got = _solve(G, g, meth, **kw)
+            assert got[0] == ref[meth][0] and np.array_equal(got[1], ref[meth][1]), meth
+        assert g.sgs_schedule()["fell_back"]
+        # a fresh handle is on the dataflow schedule again, and with the real bound it does not give up
+        g3, _ = _system(G, oracle, m, False, seed=3)
+        got = _solve(G, g3, "cg", **kw)
+        assert g3.sgs_schedule()["mode"] == "flow" and not g3.sgs_schedule()["fell_back"]
+        assert np.array_equal(got[1], ref["cg"][1])
+    o = ls.solve("cg", "sgs", **kw)
+    assert ref["cg"][0] == o["iters"] and np.abs(ref["cg"][1] - o["history"]).max() <= TOL_SOLVE
+
+
+def test_an_all_ones_nan_in_the_rhs_propagates_instead_of_stalling(G, torch, oracle):
+    """the exchange buffer's 'not computed yet' pattern is the all-ones NaN: a computed value with those
+    very bits (a 0xFF-filled rhs) is published as another NaN, so the sweep finishes at once -- the
+    solve ends with a NaN residual, not with a time-out and NALU_GPU_ESTATE"""
+    import time
+    m = oracle.BoxMesh(20, 20, 20)
+    with _Env(NG_SGS_MODE=None, NG_SGS_INPLACE=None, NG_SGS_TILE="4,4", NG_SGS_CHUNK=None):
+        g, _ = _system(G, oracle, m, False, seed=3)
+        b = np.random.RandomState(1).uniform(-1, 1, m.nnodes)
+        b.view(np.uint64)[::7] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        g.set_rhs(b)
+        t0 = time.perf_counter()
+        g.solve(G.LinearSolverConfig(method="cg", preconditioner="sgs", tolerance=1e-8, max_iterations=3))
+        assert time.perf_counter() - t0 < 5.0
+        sched = g.sgs_schedule()
+        assert sched["mode"] == "flow" and not sched["fell_back"], sched
+        assert np.isnan(g.linearResidual)
