@@ -295,13 +295,17 @@ int nalu_gpu_dot_static(int device, void *hip_stream, const double *a_dev, const
                         int64_t n, double *out_dev);
 
 /* ---- adjacent edge algorithms ---------------------------------
- * ComputeMdotEdgeAlgorithm::execute (src/ComputeMdotEdgeAlgorithm.C:67-174) */
+ * ComputeMdotEdgeAlgorithm::execute (src/ComputeMdotEdgeAlgorithm.C:67-174); export mode: only the
+ * edges this rank owns are written (the locally_owned selector, :104-106) */
 int nalu_gpu_compute_mdot_edges(nalu_gpu_linsys *h, const nalu_gpu_continuity_fields *f_dev,
                                 double dt, double gamma1, double noc_fac, double interp_together,
                                 double *mdot_dev /* n_edges */);
 /* AssembleNodalGradEdgeAlgorithm::execute + driver zeroing
- * (src/AssembleNodalGradEdgeAlgorithm.C:54-118, src/AssembleNodalGradAlgorithmDriver.C:59-123),
- * owned nodes only; ghost/shared entries are left for the caller's halo exchange. */
+ * (src/AssembleNodalGradEdgeAlgorithm.C:54-118, src/AssembleNodalGradAlgorithmDriver.C:59-123).
+ * Owner-computes mode: the complete gradient of the owned nodes (all their edges are local); the
+ * shared / ghost entries are left for nalu_gpu_halo_exchange.  Export mode: the reference's edge
+ * loop over the edges this rank owns, into owned and shared-not-owned nodes (n_owned + n_shared
+ * entries written); the driver's stk::mesh::parallel_sum (:111) is nalu_gpu_parallel_sum(h, NULL, 3, ..). */
 int nalu_gpu_nodal_grad_edges(nalu_gpu_linsys *h, nalu_gpu_vec3 edge_area_dev,
                               const double *dual_volume_dev, const double *q_dev,
                               double *gx_dev, double *gy_dev, double *gz_dev);
@@ -313,8 +317,12 @@ int nalu_gpu_nodal_grad_edges(nalu_gpu_linsys *h, nalu_gpu_vec3 edge_area_dev,
  * convention of :196-212 (relative to the edge's node 0).  hex_nodes_dev is [n_elem][8]
  * local node ids in the reference's Hex8 node order.  Sums run in ascending element order:
  * deterministic and bit-identical to the element loop.  Element edges that are not
- * registered edges of this system are skipped; volumes of shared/ghost nodes only hold the
- * local elements' share (the reference parallel_sum's them, :126-129). */
+ * registered edges of this system are skipped (owner-computes mode: an edge between two
+ * shared-not-owned nodes has no row to be found through; export mode stores those rows).  Two ways
+ * to complete the sums over ranks: owner-computes -- pass the elements around every owned node (own
+ * + one layer of the neighbours'): owned volumes and all registered edges are complete, the copies'
+ * volumes come with nalu_gpu_halo_exchange; reference style (export mode) -- pass the rank's own
+ * elements and let nalu_gpu_parallel_sum add the sharers' parts (ComputeGeometryAlgorithmDriver.C:126-133). */
 int nalu_gpu_compute_geometry_hex8(nalu_gpu_linsys *h, int64_t n_elem, const int *hex_nodes_dev,
                                    nalu_gpu_vec3 coordinates_dev, double *dual_volume_dev,
                                    double *area_x_dev, double *area_y_dev, double *area_z_dev);
@@ -391,19 +399,22 @@ int nalu_gpu_halo_exchange(nalu_gpu_linsys *h, double *vec_dev /* n_cols */);
 /* stk::mesh::parallel_sum (src/AssembleNodalGradAlgorithmDriver.C:111 for the nodal gradient,
  * src/ComputeGeometryAlgorithmDriver.C:126-133 for dual_nodal_volume and edge_area_vector): every
  * rank that shares an entity -- holds it through elements of its own -- gets the sum of all
- * sharers' values.  A share plan lists, for every neighbour of the halo plan (same order; a list
- * may be empty), the local indices of the entities (nodes, or edges in the graph's edge order)
- * shared with that neighbour, in the same order on both sides (ascending global id, as STK's comm
- * lists); an entity shared by several ranks is listed for each of them.  The values are exchanged
- * once (the comm's exchange_rows) and added in ascending rank order over all sharers, the rank's
- * own value at its own place: the same bits on every sharer.  Ghost copies (entities a rank holds
- * only because an owned node's row needs them) are not shared: nalu_gpu_halo_exchange updates
- * those.  fields_dev: n_fields (<= 16) device arrays indexed by the plan's entity index. */
+ * sharers' values.  As in STK the sum is formed on the entity's owner (own value first, then the
+ * sharers' in ascending rank order: deterministic) and sent back, two neighbour exchanges through
+ * the comm's exchange_rows; every sharer holds the owner's bits afterwards.
+ * plan == NULL: nodal fields (n_owned + n_shared + n_ghost entries each) over the halo plan's own
+ * lists; ghost copies contribute nothing and receive the totals like the shared ones.
+ * A share plan serves any other entity rank (edges, in the graph's edge order): for every neighbour
+ * of the halo plan, in its order (lists may be empty), send_ids = the entities this rank OWNS that
+ * the neighbour shares, recv_ids = the entities the neighbour owns that this rank shares, each list
+ * in the same order as its counterpart on the neighbour (ascending global id, as STK's comm lists).
+ * fields_dev: n_fields (<= 16) device arrays indexed by entity. */
 typedef struct nalu_gpu_share_plan nalu_gpu_share_plan;
-int nalu_gpu_share_plan_create(nalu_gpu_linsys *h, const int *offsets /* n_neighbors + 1 */,
-                               const int *local_ids, int64_t n_entities, nalu_gpu_share_plan **out);
+int nalu_gpu_share_plan_create(nalu_gpu_linsys *h, const int *send_offsets, const int *send_ids,
+                               const int *recv_offsets, const int *recv_ids, int64_t n_entities,
+                               nalu_gpu_share_plan **out);
 int nalu_gpu_share_plan_destroy(nalu_gpu_share_plan *p);
-int nalu_gpu_parallel_sum(nalu_gpu_linsys *h, nalu_gpu_share_plan *p, int n_fields,
+int nalu_gpu_parallel_sum(nalu_gpu_linsys *h, nalu_gpu_share_plan *plan, int n_fields,
                           double *const *fields_dev);
 
 /* ---- timers: EquationSystem's buckets (src/EquationSystem.C:270-292) measured with HIP

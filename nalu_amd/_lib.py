@@ -177,7 +177,7 @@ def load():
         "nalu_gpu_set_debug": [vp, ci],
         "nalu_gpu_dot_static": [ci, vp, vp, vp, i64, vp],
         "nalu_gpu_update_and_clip": [vp, i64, vp, vp, vp, dbl, vp],
-        "nalu_gpu_share_plan_create": [vp, vp, vp, i64, P(vp)],
+        "nalu_gpu_share_plan_create": [vp, vp, vp, vp, vp, i64, P(vp)],
         "nalu_gpu_share_plan_destroy": [vp],
         "nalu_gpu_parallel_sum": [vp, vp, ci, vp],
     }

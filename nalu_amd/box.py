@@ -300,3 +300,104 @@ class BoxBlock:
     coords = BoxSlab.coords
     _frac = BoxSlab._frac
     uniform_geometry = BoxSlab.uniform_geometry
+
+
+# ---------------------------------------------------------------------------------------------
+# Reference-style ("export mode") bookkeeping of a partition: the elements a rank owns, the edges of
+# those elements, who owns and who shares an edge -- what STK's comm lists give the reference
+# (src/ComputeGeometryAlgorithmDriver.C:126-133 sums edge_area_vector over the sharers).
+HEX_EDGES = ((0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7))
+
+
+def _parts(S):
+    return S.parts if isinstance(S, BoxBlock) else (1, 1, S.nranks)
+
+
+def _dim_ranges(S):
+    """per dimension: the inclusive node range of every part's bricks"""
+    return [split_elems(S.dims[d] - 1, _parts(S)[d]) for d in range(3)]
+
+
+def _lid_lookup(S):
+    order = np.argsort(S.gids, kind="stable")
+    sg = S.gids[order]
+
+    def look(g):
+        pos = np.searchsorted(sg, g)
+        assert np.array_equal(sg[pos], g), "node is not held by this rank"
+        return order[pos]
+    return look
+
+
+def own_hex_nodes(S):
+    """(n_elem, 8) int32 local node ids of the Hex8 elements of the rank's OWN brick (its elements in the
+    reference's sense; BoxSlab.hex_nodes() also returns the neighbour's first layer)"""
+    px, py, pz = _parts(S)
+    c = (S.rank % px, (S.rank // px) % py, S.rank // (px * py))
+    r = [_dim_ranges(S)[d][c[d]] for d in range(3)]
+    nxn, nyn, _ = S.dims
+    i, j, k = np.meshgrid(np.arange(r[0][0], r[0][1]), np.arange(r[1][0], r[1][1]), np.arange(r[2][0], r[2][1]),
+                          indexing="ij")
+    n0 = (1 + i + nxn * (j + nyn * k)).transpose(2, 1, 0).reshape(-1).astype(np.int64)
+    sx, sy, sz = 1, nxn, nxn * nyn
+    h = np.stack([n0, n0 + sx, n0 + sx + sy, n0 + sy, n0 + sz, n0 + sx + sz, n0 + sx + sy + sz, n0 + sy + sz], axis=1)
+    return np.ascontiguousarray(_lid_lookup(S)(h.reshape(-1)).reshape(-1, 8).astype(np.int32))
+
+
+def reference_edges(S, hexes=None):
+    """The rank's edge list in the reference's sense: S.edge_nodes (every edge that touches an owned node:
+    the graph needs them) followed by the edges of the rank's own elements between two shared-not-owned
+    nodes.  Returns (edge_nodes, owner, send, recv): owner[e] = the rank that owns edge e (the lowest
+    rank whose elements hold it; -1: no element of this rank holds it, it only shapes the graph), and the
+    share lists of nalu_gpu_share_plan_create as {neighbour rank: local edge indices}, ascending global
+    (L, R) on both sides."""
+    hexes = own_hex_nodes(S) if hexes is None else hexes
+    g = S.gids
+    M = int(g.max()) + 1
+    have = g[S.edge_nodes[:, 0]].astype(np.int64) * M + g[S.edge_nodes[:, 1]]
+    pairs = np.concatenate([hexes[:, [a, b]] for a, b in HEX_EDGES]).astype(np.int64)
+    flip = g[pairs[:, 0]] > g[pairs[:, 1]]
+    pairs[flip] = pairs[flip][:, ::-1]
+    key = g[pairs[:, 0]] * M + g[pairs[:, 1]]
+    ukey, first = np.unique(key, return_index=True)
+    extra = ~np.isin(ukey, have)
+    en = np.concatenate([S.edge_nodes, pairs[first[extra]].astype(np.int32)])
+    # sharers of an edge: the parts whose node range holds both ends, per dimension
+    rng = _dim_ranges(S)
+    px, py, pz = _parts(S)
+    idx = (S.i.astype(np.int64), S.j.astype(np.int64), S.k.astype(np.int64))
+    holds = []  # per dimension: (n_edges, parts) bool
+    for d in range(3):
+        a, b = idx[d][en[:, 0]], idx[d][en[:, 1]]
+        lo, hi = np.minimum(a, b), np.maximum(a, b)
+        holds.append(np.stack([(lo >= r0) & (hi <= r1) for r0, r1 in rng[d]], axis=1))
+    rank_holds = np.zeros((len(en), px * py * pz), bool)
+    for q in range(px * py * pz):
+        rank_holds[:, q] = holds[0][:, q % px] & holds[1][:, (q // px) % py] & holds[2][:, q // (px * py)]
+    owner = np.where(rank_holds[:, S.rank], rank_holds.argmax(axis=1), -1).astype(np.int32)
+    ekey = g[en[:, 0]].astype(np.int64) * M + g[en[:, 1]]
+    send, recv = {}, {}
+    for q in range(px * py * pz):
+        if q == S.rank:
+            continue
+        mine = np.nonzero((owner == S.rank) & rank_holds[:, q])[0]
+        theirs = np.nonzero(owner == q)[0]
+        if len(mine):
+            send[q] = mine[np.argsort(ekey[mine])].astype(np.int32)
+        if len(theirs):
+            recv[q] = theirs[np.argsort(ekey[theirs])].astype(np.int32)
+    return np.ascontiguousarray(en), owner, send, recv
+
+
+def share_plan_arrays(S, send, recv):
+    """{rank: ids} dictionaries -> the (offsets, ids) arrays of nalu_gpu_share_plan_create, one list per
+    halo neighbour of S in its order"""
+    so, si, ro, ri = [0], [], [0], []
+    for q in [int(v) for v in S.neighbors]:
+        si.append(send.get(q, np.zeros(0, np.int32)))
+        ri.append(recv.get(q, np.zeros(0, np.int32)))
+        so.append(so[-1] + len(si[-1]))
+        ro.append(ro[-1] + len(ri[-1]))
+    assert set(send) | set(recv) <= set(int(v) for v in S.neighbors), "an edge is shared with a rank that is no halo neighbour"
+    cat = lambda l: np.concatenate(l).astype(np.int32) if l else np.zeros(0, np.int32)
+    return np.array(so, np.int32), cat(si), np.array(ro, np.int32), cat(ri)

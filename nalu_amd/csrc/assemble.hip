@@ -1010,10 +1010,12 @@ bool vec3_ok(const nalu_gpu_vec3 &v) { return v.x && v.y && v.z; }
 // ------------------------------------------------------------------ mdot / gradient
 __global__ __launch_bounds__(256) void k_mdot(long long nEdges, const int *__restrict__ eL,
                                                const int *__restrict__ eR, ContParams P,
-                                               double *__restrict__ mdot)
+                                               double *__restrict__ mdot,
+                                               const unsigned char *__restrict__ edgeOwned)
 {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nEdges) return;
+  if (edgeOwned && !edgeOwned[e]) return;  // export mode: the edge's owner computes its mass flow
   double lhsfac;
   mdot[e] = ContOp::flux(P, ContOp::load_edge(P, e), ContOp::load(P, eL[e]), ContOp::load(P, eR[e]), lhsfac);
 }
@@ -1041,6 +1043,7 @@ __global__ __launch_bounds__(SELL_C) void k_nodal_grad(SellView A, nalu_gpu_vec3
     const unsigned tag = A.tags[pos];
     if (tag >= TAG_OTHER) continue;
     const long long e = tag & 0x7FFFFFFFu;
+    if (A.edgeOwned && !A.edgeOwned[e]) continue;  // export mode: only the edges this rank owns (the reference's selector)
     const bool isR = (tag >> 31) != 0;
     const double qn = q[A.cols[pos]];
     const double qip = isR ? 0.5 * (qn + qi) : 0.5 * (qi + qn);
@@ -1233,7 +1236,8 @@ extern "C" int nalu_gpu_compute_mdot_edges(nalu_gpu_linsys *h, const nalu_gpu_co
   P.noc = noc_fac;
   P.interp = interp_together;
   if (h->nEdges)
-    k_mdot<<<(unsigned)((h->nEdges + 255) / 256), 256, 0, h->stream>>>(h->nEdges, h->dEdgeL, h->dEdgeR, P, mdot_dev);
+    k_mdot<<<(unsigned)((h->nEdges + 255) / 256), 256, 0, h->stream>>>(h->nEdges, h->dEdgeL, h->dEdgeR, P, mdot_dev,
+                                                                       h->dEdgeOwned);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
 }
@@ -1243,8 +1247,11 @@ extern "C" int nalu_gpu_nodal_grad_edges(nalu_gpu_linsys *h, nalu_gpu_vec3 area,
 {
   NG_FINALIZED(h);
   NG_REQUIRE(vec3_ok(area) && vol && q && gx && gy && gz, NALU_GPU_EINVAL, "nodal grad: null pointer");
-  if (h->nSlicesOwned)
-    k_nodal_grad<<<h->nSlicesOwned, SELL_C, 0, h->stream>>>(sell_view(h), area, vol, q, gx, gy, gz);
+  // owner-computes mode: the complete sums of the owned nodes (every edge that touches them is local).
+  // Export mode: the reference's edge loop -- this rank's own edges only, into the owned AND the
+  // shared-not-owned nodes; nalu_gpu_parallel_sum(h, NULL, 3, ...) then plays the driver's part.
+  if (h->nSlices)
+    k_nodal_grad<<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view_all(h), area, vol, q, gx, gy, gz);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
 }

@@ -187,7 +187,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dFlowT);
   NG_FREE(h->dY); NG_FREE(h->dList); NG_FREE(h->dSendLids); NG_FREE(h->dSendBuf);
   NG_FREE(h->dRecvBuf); NG_FREE(h->dRecvLids); NG_FREE(h->dEdgeOwned); NG_FREE(h->dExpSendRow); NG_FREE(h->dExpRecvRow);
-  NG_FREE(h->dExpRecvPos); NG_FREE(h->dExpSend); NG_FREE(h->dExpRecv);
+  NG_FREE(h->dExpRecvPos); NG_FREE(h->dExpSend); NG_FREE(h->dExpRecv); NG_FREE(h->dPsA); NG_FREE(h->dPsB);
   if (h->hPinned) (void)hipHostFree(h->hPinned);
   if (h->ownStream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1850,44 +1850,32 @@ extern "C" int nalu_gpu_halo_exchange(nalu_gpu_linsys *h, double *vec_dev)
 
 // ---------------------------------------------------------------- parallel_sum
 // stk::mesh::parallel_sum (src/AssembleNodalGradAlgorithmDriver.C:111, src/ComputeGeometryAlgorithmDriver.C:
-// 126-133): every sharer of an entity ends up with the sum of all sharers' values.  Here: pack the
-// shared entities' values per neighbour, one neighbour exchange (exchange_rows), then the sum
-// 0 + v_r1 + v_r2 + ... over ALL sharers in ascending rank order, the rank's own value at its own
-// place -- the same expression on every sharer, hence the same bits everywhere (STK sums on the
-// owner and sends the result back; the effect is the same).
+// 126-133): every sharer of an entity ends up with the sum of all sharers' values.  As in STK the sum
+// is formed on the entity's owner and sent back: (1) every rank sends the values of the entities it
+// shares but does not own to their owners, (2) the owner adds them to its own value, neighbour after
+// neighbour in ascending rank order (a fixed order: deterministic), (3) the totals travel back the
+// same way.  Two neighbour exchanges through the comm's exchange_rows; every sharer holds the
+// owner's bits afterwards.
 struct nalu_gpu_share_plan {
   nalu_gpu_linsys *h = nullptr;
-  int64_t nEntities = 0, nList = 0, nUniq = 0;
-  std::vector<int> off;   // per halo neighbour
-  int *dIds = nullptr;    // the lists, neighbour after neighbour
-  int *dUniq = nullptr;   // every shared entity once
-  double *dSend = nullptr, *dRecv = nullptr, *dStash = nullptr;
-  int cap = 0;            // fields the buffers hold
+  int64_t nEntities = 0;
+  std::vector<int> so, ro;  // per halo neighbour: owned entities it shares / entities it owns that this rank shares
+  int *dSendIds = nullptr, *dRecvIds = nullptr;
 };
 
 namespace {
 constexpr int PS_MAX_FIELDS = 16;
 struct PsFields { double *f[PS_MAX_FIELDS]; };
 
-__global__ void k_ps_pack(long long n, const int *__restrict__ ids, PsFields F, int nF, double *__restrict__ out)
+// ids == nullptr: entity base + i.  Entities from zeroFrom on contribute nothing (ghost copies)
+__global__ void k_ps_pack(long long n, const int *__restrict__ ids, int base, int zeroFrom, PsFields F, int nF,
+                          double *__restrict__ out)
 {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int id = ids[i];
-  for (int f = 0; f < nF; ++f) out[i * nF + f] = F.f[f][id];
+  const int id = ids ? ids[i] : base + (int)i;
+  for (int f = 0; f < nF; ++f) out[i * nF + f] = id >= zeroFrom ? 0.0 : F.f[f][id];
 }
-// own values aside, the entity zeroed: the sum starts from 0 on every sharer
-__global__ void k_ps_stash(long long n, const int *__restrict__ uniq, PsFields F, int nF, double *__restrict__ stash)
-{
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int id = uniq[i];
-  for (int f = 0; f < nF; ++f) {
-    stash[i * nF + f] = F.f[f][id];
-    F.f[f][id] = 0.0;
-  }
-}
-// one sharer's values added (an entity appears at most once in a list)
 __global__ void k_ps_add(long long n, const int *__restrict__ ids, PsFields F, int nF, const double *__restrict__ in)
 {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1895,42 +1883,61 @@ __global__ void k_ps_add(long long n, const int *__restrict__ ids, PsFields F, i
   const int id = ids[i];
   for (int f = 0; f < nF; ++f) F.f[f][id] += in[i * nF + f];
 }
+__global__ void k_ps_unpack(long long n, const int *__restrict__ ids, int base, PsFields F, int nF,
+                            const double *__restrict__ in)
+{
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int id = ids ? ids[i] : base + (int)i;
+  for (int f = 0; f < nF; ++f) F.f[f][id] = in[i * nF + f];
+}
+
+int check_id_lists(const nalu_gpu_linsys *h, const int *off, const int *ids, int64_t nEnt, const char *what)
+{
+  NG_REQUIRE(off[0] == 0, NALU_GPU_EINVAL, "share plan: %s offsets must start at 0", what);
+  for (int p = 0; p < h->nNbr; ++p) {
+    NG_REQUIRE(off[p] <= off[p + 1], NALU_GPU_EINVAL, "share plan: %s offsets must not decrease", what);
+    std::vector<int> one(ids + off[p], ids + off[p + 1]);
+    for (int id : one)
+      NG_REQUIRE(id >= 0 && id < nEnt, NALU_GPU_EINVAL, "share plan: %s entity %d outside [0,%lld)", what, id, (long long)nEnt);
+    std::sort(one.begin(), one.end());
+    NG_REQUIRE(std::adjacent_find(one.begin(), one.end()) == one.end(), NALU_GPU_EINVAL,
+               "share plan: an entity is listed twice in the %s list of neighbour rank %d", what, h->nbrRanks[p]);
+  }
+  return NALU_GPU_OK;
+}
 }  // namespace
 
-extern "C" int nalu_gpu_share_plan_create(nalu_gpu_linsys *h, const int *offsets, const int *local_ids,
-                                          int64_t n_entities, nalu_gpu_share_plan **out)
+extern "C" int nalu_gpu_share_plan_create(nalu_gpu_linsys *h, const int *send_offsets, const int *send_ids,
+                                          const int *recv_offsets, const int *recv_ids, int64_t n_entities,
+                                          nalu_gpu_share_plan **out)
 {
   NG_FINALIZED(h);
   NG_REQUIRE(out && n_entities >= 0, NALU_GPU_EINVAL, "share plan: bad arguments");
   const int nN = h->nNbr;
-  NG_REQUIRE(nN == 0 || offsets, NALU_GPU_EINVAL, "share plan: one list per halo neighbour (set the halo plan first)");
-  const int64_t nl = nN ? offsets[nN] : 0;
-  NG_REQUIRE(nl == 0 || local_ids, NALU_GPU_EINVAL, "share plan: null list");
-  std::vector<int> uniq;
-  for (int p = 0; p < nN; ++p) {
-    NG_REQUIRE(offsets[p] <= offsets[p + 1] && offsets[0] == 0, NALU_GPU_EINVAL, "share plan: offsets must start at 0 and not decrease");
-    std::vector<int> one(local_ids + offsets[p], local_ids + offsets[p + 1]);
-    for (int id : one)
-      NG_REQUIRE(id >= 0 && id < n_entities, NALU_GPU_EINVAL, "share plan: entity %d outside [0,%lld)", id, (long long)n_entities);
-    std::sort(one.begin(), one.end());
-    NG_REQUIRE(std::adjacent_find(one.begin(), one.end()) == one.end(), NALU_GPU_EINVAL,
-               "share plan: an entity is listed twice for neighbour rank %d", h->nbrRanks[p]);
-    uniq.insert(uniq.end(), one.begin(), one.end());
+  NG_REQUIRE(nN == 0 || (send_offsets && recv_offsets), NALU_GPU_EINVAL,
+             "share plan: one pair of lists per halo neighbour (set the halo plan first)");
+  const int64_t ns = nN ? send_offsets[nN] : 0, nr = nN ? recv_offsets[nN] : 0;
+  NG_REQUIRE((ns == 0 || send_ids) && (nr == 0 || recv_ids), NALU_GPU_EINVAL, "share plan: null list");
+  if (nN) {
+    NG_TRY(check_id_lists(h, send_offsets, send_ids, n_entities, "owned"));
+    NG_TRY(check_id_lists(h, recv_offsets, recv_ids, n_entities, "shared"));
   }
-  std::sort(uniq.begin(), uniq.end());
-  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
   nalu_gpu_share_plan *P = new nalu_gpu_share_plan();
   P->h = h;
   P->nEntities = n_entities;
-  P->nList = nl;
-  P->nUniq = (int64_t)uniq.size();
-  if (nN) P->off.assign(offsets, offsets + nN + 1);
-  else P->off.assign(1, 0);
-  *out = P;  // (released by the caller also when one of the copies below fails)
-  NG_HIP(hipMalloc(&P->dIds, sizeof(int) * (size_t)std::max<int64_t>(nl, 1)));
-  NG_HIP(hipMalloc(&P->dUniq, sizeof(int) * std::max<size_t>(uniq.size(), 1)));
-  if (nl) NG_HIP(hipMemcpy(P->dIds, local_ids, sizeof(int) * (size_t)nl, hipMemcpyHostToDevice));
-  if (!uniq.empty()) NG_HIP(hipMemcpy(P->dUniq, uniq.data(), sizeof(int) * uniq.size(), hipMemcpyHostToDevice));
+  if (nN) {
+    P->so.assign(send_offsets, send_offsets + nN + 1);
+    P->ro.assign(recv_offsets, recv_offsets + nN + 1);
+  } else {
+    P->so.assign(1, 0);
+    P->ro.assign(1, 0);
+  }
+  *out = P;  // (the caller destroys it also when a copy below fails)
+  NG_HIP(hipMalloc(&P->dSendIds, sizeof(int) * (size_t)std::max<int64_t>(ns, 1)));
+  NG_HIP(hipMalloc(&P->dRecvIds, sizeof(int) * (size_t)std::max<int64_t>(nr, 1)));
+  if (ns) NG_HIP(hipMemcpy(P->dSendIds, send_ids, sizeof(int) * (size_t)ns, hipMemcpyHostToDevice));
+  if (nr) NG_HIP(hipMemcpy(P->dRecvIds, recv_ids, sizeof(int) * (size_t)nr, hipMemcpyHostToDevice));
   return NALU_GPU_OK;
 }
 
@@ -1939,7 +1946,7 @@ extern "C" int nalu_gpu_share_plan_destroy(nalu_gpu_share_plan *P)
   if (!P) return NALU_GPU_OK;
   nalu_gpu::DeviceGuard ngGuard_(P->h->device);
   (void)hipStreamSynchronize(P->h->stream);
-  NG_FREE(P->dIds); NG_FREE(P->dUniq); NG_FREE(P->dSend); NG_FREE(P->dRecv); NG_FREE(P->dStash);
+  NG_FREE(P->dSendIds); NG_FREE(P->dRecvIds);
   delete P;
   return NALU_GPU_OK;
 }
@@ -1948,7 +1955,7 @@ extern "C" int nalu_gpu_parallel_sum(nalu_gpu_linsys *h, nalu_gpu_share_plan *P,
                                      double *const *fields_dev)
 {
   NG_FINALIZED(h);
-  NG_REQUIRE(P && P->h == h, NALU_GPU_EINVAL, "parallel_sum: the plan belongs to another linear system");
+  NG_REQUIRE(!P || P->h == h, NALU_GPU_EINVAL, "parallel_sum: the plan belongs to another linear system");
   NG_REQUIRE(n_fields >= 1 && n_fields <= PS_MAX_FIELDS && fields_dev, NALU_GPU_EINVAL,
              "parallel_sum: 1..%d fields per call (got %d)", PS_MAX_FIELDS, n_fields);
   PsFields F;
@@ -1958,42 +1965,49 @@ extern "C" int nalu_gpu_parallel_sum(nalu_gpu_linsys *h, nalu_gpu_share_plan *P,
   }
   const int nN = h->nNbr;
   if (nN == 0) return NALU_GPU_OK;  // one rank: nothing is shared
-  NG_REQUIRE((int)P->off.size() == nN + 1, NALU_GPU_ESTATE, "parallel_sum: the halo plan changed since the share plan was made");
   NG_REQUIRE(h->hasComm && h->comm.exchange_rows, NALU_GPU_ESTATE,
              "parallel_sum needs a comm with exchange_rows (nalu_gpu_set_comm)");
-  if (n_fields > P->cap) {
+  // plan == null: nodal fields through the halo plan's own lists; ghost copies send zeros and
+  // receive the totals like the shared ones
+  const std::vector<int> &so = P ? P->so : h->sendOff, &ro = P ? P->ro : h->recvOff;
+  NG_REQUIRE((int)so.size() == nN + 1 && (int)ro.size() == nN + 1, NALU_GPU_ESTATE,
+             "parallel_sum: the halo plan changed since the share plan was made");
+  const int *sendIds = P ? P->dSendIds : h->dSendLids;
+  const int *recvIds = P ? P->dRecvIds : h->dRecvLids;  // (null: columns nOwned + i)
+  const int zeroFrom = P ? 0x7FFFFFFF : h->nOwned + h->nShared;
+  const long long ns = so[nN], nr = ro[nN];
+  // staging: the scatter-plan style "grow on demand" pair, kept on the handle
+  const size_t need = sizeof(double) * (size_t)std::max<long long>(std::max(ns, nr), 1) * n_fields;
+  if (need > h->psBytes) {
     NG_HIP(hipStreamSynchronize(h->stream));
-    NG_FREE(P->dSend); NG_FREE(P->dRecv); NG_FREE(P->dStash);
-    const size_t nb = sizeof(double) * (size_t)std::max<int64_t>(P->nList, 1) * n_fields;
-    NG_HIP(hipMalloc(&P->dSend, nb));
-    NG_HIP(hipMalloc(&P->dRecv, nb));
-    NG_HIP(hipMalloc(&P->dStash, sizeof(double) * (size_t)std::max<int64_t>(P->nUniq, 1) * n_fields));
-    P->cap = n_fields;
+    NG_FREE(h->dPsA); NG_FREE(h->dPsB);
+    NG_HIP(hipMalloc(&h->dPsA, need));
+    NG_HIP(hipMalloc(&h->dPsB, need));
+    h->psBytes = need;
   }
   auto grid = [](long long n) { return (unsigned)((n + 255) / 256); };
-  if (P->nList) k_ps_pack<<<grid(P->nList), 256, 0, h->stream>>>(P->nList, P->dIds, F, n_fields, P->dSend);
+  std::vector<int64_t> so64((size_t)nN + 1), ro64((size_t)nN + 1);
+  for (int p = 0; p <= nN; ++p) { so64[p] = (int64_t)so[p] * n_fields; ro64[p] = (int64_t)ro[p] * n_fields; }
+  // (1) the sharers' values to the owners
+  if (nr) k_ps_pack<<<grid(nr), 256, 0, h->stream>>>(nr, recvIds, h->nOwned, zeroFrom, F, n_fields, h->dPsA);
   NG_HIP(hipGetLastError());
-  std::vector<int64_t> off((size_t)nN + 1);
-  for (int p = 0; p <= nN; ++p) off[p] = (int64_t)P->off[p] * n_fields;
-  NG_REQUIRE(h->comm.exchange_rows(h->comm.ctx, P->dSend, off.data(), P->dRecv, off.data(), h->stream) == 0,
+  NG_REQUIRE(h->comm.exchange_rows(h->comm.ctx, h->dPsA, ro64.data(), h->dPsB, so64.data(), h->stream) == 0,
              NALU_GPU_EHIP, "exchange_rows callback failed: %s", callback_error());
-  if (P->nUniq) k_ps_stash<<<grid(P->nUniq), 256, 0, h->stream>>>(P->nUniq, P->dUniq, F, n_fields, P->dStash);
-  // ascending rank order, this rank at its own place
+  // (2) added on the owner, neighbours in ascending rank order
   std::vector<int> order((size_t)nN);
   for (int p = 0; p < nN; ++p) order[p] = p;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->nbrRanks[a] < h->nbrRanks[b]; });
-  bool ownDone = false;
-  auto addOwn = [&]() {
-    if (!ownDone && P->nUniq) k_ps_add<<<grid(P->nUniq), 256, 0, h->stream>>>(P->nUniq, P->dUniq, F, n_fields, P->dStash);
-    ownDone = true;
-  };
   for (int q = 0; q < nN; ++q) {
     const int p = order[q];
-    if (h->nbrRanks[p] > h->myRank) addOwn();
-    const long long n = P->off[p + 1] - P->off[p];
-    if (n) k_ps_add<<<grid(n), 256, 0, h->stream>>>(n, P->dIds + P->off[p], F, n_fields, P->dRecv + off[p]);
+    const long long n = so[p + 1] - so[p];
+    if (n) k_ps_add<<<grid(n), 256, 0, h->stream>>>(n, sendIds + so[p], F, n_fields, h->dPsB + so64[p]);
   }
-  addOwn();
+  // (3) the totals back to the sharers
+  if (ns) k_ps_pack<<<grid(ns), 256, 0, h->stream>>>(ns, sendIds, 0, 0x7FFFFFFF, F, n_fields, h->dPsB);
+  NG_HIP(hipGetLastError());
+  NG_REQUIRE(h->comm.exchange_rows(h->comm.ctx, h->dPsB, so64.data(), h->dPsA, ro64.data(), h->stream) == 0,
+             NALU_GPU_EHIP, "exchange_rows callback failed: %s", callback_error());
+  if (nr) k_ps_unpack<<<grid(nr), 256, 0, h->stream>>>(nr, recvIds, h->nOwned, F, n_fields, h->dPsA);
   NG_HIP(hipGetLastError());
   return NALU_GPU_OK;
 }

@@ -376,7 +376,9 @@ extern "C" int nalu_gpu_compute_geometry_hex8(nalu_gpu_linsys *h, int64_t n_elem
   NG_HIP(hipMemsetAsync(edgeCur.p, 0, sizeof(int) * (size_t)std::max<long long>(nE, 1), h->stream));
   NG_HIP(hipMemsetAsync(err.p, 0, sizeof(int), h->stream));
   const unsigned nbEl = (unsigned)((n_elem + 255) / 256);
-  const SellView A = sell_view(h);
+  // (every stored row: in export mode also the rows of the shared-not-owned nodes, so that the edges
+  // between two shared nodes -- part of this rank's elements, owned by a lower rank -- are found)
+  const SellView A = sell_view_all(h);
   if (n_elem)
     k_geom_adjacency<false><<<nbEl, 256, 0, h->stream>>>(n_elem, hex_nodes_dev, A, nN, nodeCur.as<int>(),
                                                          edgeCur.as<int>(), nullptr, nullptr,

@@ -177,6 +177,8 @@ struct nalu_gpu_linsys {
   long long *dExpRecvPos = nullptr;             // SELL position of every received entry (-1: padding)
   std::vector<int64_t> expRecvPosOff;           // per neighbour offsets into dExpRecvPos
   double *dExpSend = nullptr, *dExpRecv = nullptr;
+  double *dPsA = nullptr, *dPsB = nullptr;  // staging of nalu_gpu_parallel_sum
+  size_t psBytes = 0;
   std::vector<int64_t> gids;
   std::vector<int> owners;
   std::vector<EntBlock> blocks;

@@ -96,12 +96,13 @@ class ScatterPlan:
 class SharePlan:
     """nalu_gpu_share_plan: the shared entities of every halo neighbour (stk::mesh::parallel_sum)."""
 
-    def __init__(self, owner, offsets, local_ids, n_entities):
-        off, ids = _np(offsets, np.int32), _np(local_ids, np.int32)
+    def __init__(self, owner, send_offsets, send_ids, recv_offsets, recv_ids, n_entities):
+        so, si = _np(send_offsets, np.int32), _np(send_ids, np.int32)
+        ro, ri = _np(recv_offsets, np.int32), _np(recv_ids, np.int32)
         self.owner, self.n_entities = owner, int(n_entities)
         self.p = C.c_void_p()
-        L.check(owner.lib.nalu_gpu_share_plan_create(owner.h, off.ctypes.data, ids.ctypes.data, self.n_entities,
-                                                     C.byref(self.p)))
+        L.check(owner.lib.nalu_gpu_share_plan_create(owner.h, so.ctypes.data, si.ctypes.data, ro.ctypes.data,
+                                                     ri.ctypes.data, self.n_entities, C.byref(self.p)))
 
     def close(self):
         if self.p and self.owner.h:  # (before its linear system goes away)
@@ -443,7 +444,7 @@ class GpuLinearSystem:
     def nodal_grad_edges(self, edge_area, dual_volume, q, grad_out):
         self._check_fields(dual_volume, q, edge_area=edge_area)
         g = _vec3(grad_out)
-        assert grad_out.shape[1] >= self.n_rows
+        assert grad_out.shape[1] >= self.n_cols  # (export mode also writes the shared-not-owned entries)
         L.check(self.lib.nalu_gpu_nodal_grad_edges(self.h, _vec3(edge_area), _ptr(dual_volume),
                                                    _ptr(q), g.x, g.y, g.z))
 
@@ -490,17 +491,20 @@ class GpuLinearSystem:
                                                   None if info is None else info.ctypes.data))
         return info
 
-    def createSharePlan(self, offsets, local_ids, n_entities):
-        """share plan of stk::mesh::parallel_sum: per halo neighbour the local indices of the shared entities"""
-        return SharePlan(self, offsets, local_ids, n_entities)
+    def createSharePlan(self, send_offsets, send_ids, recv_offsets, recv_ids, n_entities):
+        """share plan of stk::mesh::parallel_sum for non-nodal entities (edges): per halo neighbour the owned
+        entities it shares (send) and the entities it owns that this rank shares (recv)"""
+        return SharePlan(self, send_offsets, send_ids, recv_offsets, recv_ids, n_entities)
 
-    def parallel_sum(self, plan, fields):
-        """stk::mesh::parallel_sum of device arrays (each indexed by the plan's entity index)"""
-        assert plan.owner is self and 1 <= len(fields) <= 16
+    def parallel_sum(self, fields, plan=None):
+        """stk::mesh::parallel_sum of device arrays: nodal fields (plan None, n_cols entries each) or the
+        entities of a share plan"""
+        assert (plan is None or plan.owner is self) and 1 <= len(fields) <= 16
+        n = self.n_cols if plan is None else plan.n_entities
         for t in fields:
-            assert t.dim() == 1 and t.is_contiguous() and t.element_size() == 8 and t.numel() >= plan.n_entities
+            assert t.dim() == 1 and t.stride(0) == 1 and t.element_size() == 8 and t.numel() >= n
         ptrs = (C.c_void_p * len(fields))(*[t.data_ptr() for t in fields])
-        L.check(self.lib.nalu_gpu_parallel_sum(self.h, plan.p, len(fields), ptrs))
+        L.check(self.lib.nalu_gpu_parallel_sum(self.h, None if plan is None else plan.p, len(fields), ptrs))
 
     def set_halo_plan(self, neighbor_ranks, send_offsets, send_lids, recv_offsets, recv_lids=None):
         nb = _np(neighbor_ranks, np.int32)

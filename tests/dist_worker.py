@@ -671,6 +671,123 @@ def loopback_test(rank, world):
     print("loopback: interior slices", li["n_slices"], flush=True)
 
 
+def adjacent_test(rank, world, kind):
+    """the adjacent algorithms on several ranks against the np = 1 oracle, on owned
+    AND shared / ghost entries, both ways the library supports:
+      owner   (slabs)         every rank is given the elements / edges around its owned nodes; owned
+                              sums are complete, copies come with nalu_gpu_halo_exchange;
+      export  (slabs, bricks) the reference's way: own elements and own edges only, partial sums at
+                              shared nodes / edges, completed by nalu_gpu_parallel_sum
+                              (stk::mesh::parallel_sum, src/AssembleNodalGradAlgorithmDriver.C:111,
+                              src/ComputeGeometryAlgorithmDriver.C:126-133), then the export-mode assembly."""
+    from oracle import pyoracle as po
+    from common import Case, rel_err
+    from nalu_amd.comm import TorchComm
+    from nalu_amd.box import BoxBlock, own_hex_nodes, reference_edges, share_plan_arrays
+    block = kind == "export_block"
+    export = kind.startswith("export")
+    dims = (9, 8, 9) if block else (7, 6, 17)
+    c = Case(po, 0, 0.125, dims=dims)
+    S = BoxBlock(*dims, rank, (2, 2, 2)) if block else nalu_amd.BoxSlab(*dims, rank, world)
+    gi = S.gids - 1
+    nO, nS, nL = S.n_owned, S.n_shared, S.n_local
+    if export:
+        edge_nodes, eowner, send, recv = reference_edges(S)
+        hexes = own_hex_nodes(S)
+    else:
+        edge_nodes, eowner, hexes = S.edge_nodes, None, S.hex_nodes()
+    key = c.m.edge_nodes[:, 0].astype(np.int64) * c.m.nnodes + c.m.edge_nodes[:, 1]
+    lk = gi[edge_nodes[:, 0]] * c.m.nnodes + gi[edge_nodes[:, 1]]
+    ge = np.searchsorted(key, lk)
+    assert np.array_equal(key[ge], lk)
+    dev = "cuda:0"
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    g = nalu_amd.GpuLinearSystem(1, 0, torch.cuda.current_stream().cuda_stream)
+    if export:
+        g.set_assembly_mode("export")
+    g.beginLinearSystemConstruction(nO, nS, S.n_ghost, S.gids, S.owners, rank)
+    g.buildEdgeToNodeGraph(edge_nodes)
+    if export:
+        g.set_edge_ownership(eowner == rank)
+    g.finalizeLinearSystem()
+    g.set_halo_plan(S.neighbors, S.send_offsets, S.send_lids, S.recv_offsets, getattr(S, "recv_lids", None))
+    comm = TorchComm(g, S.neighbors, S.send_offsets, S.recv_offsets, dev)
+    ne = len(edge_nodes)
+    tol = 1e-12
+
+    # ---- geometry: dual nodal volume and edge area vectors from the Hex8 elements
+    coords = t(c.m.xyz[gi].T)
+    vol = torch.full((nL,), -7.0, dtype=torch.float64, device=dev)
+    area = torch.full((3, ne), -7.0, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    g.compute_geometry_hex8(t(hexes).to(torch.int32), coords, vol, area)
+    held = np.ones(ne, bool)  # edges whose area this rank has to know
+    if export:
+        plan = g.createSharePlan(*share_plan_arrays(S, send, recv), ne)
+        g.parallel_sum([vol])                          # nodal: the halo plan's lists
+        g.parallel_sum([area[0], area[1], area[2]], plan)  # edges: their own share lists
+        held = eowner >= 0
+    else:
+        g.halo_exchange(vol)
+    g.synchronize()
+    assert rel_err(vol.cpu().numpy(), c.vol[gi]) <= tol, "dual volume"
+    assert rel_err(area.cpu().numpy().T[held], c.area[ge][held]) <= tol, "edge area"
+    # (the rest runs on the oracle's geometry: every step is checked on its own)
+    area_in = c.area[ge].copy()
+    area_in[~held] = np.nan  # what this rank does not hold must not be used
+    area_d, vol_d = t(area_in.T), t(c.vol[gi])
+
+    # ---- projected nodal gradient of q
+    q = t(c.q[gi])
+    grad = torch.full((3, nL), -7.0, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    g.nodal_grad_edges(area_d, vol_d, q, grad)
+    if export:
+        g.parallel_sum([grad[0], grad[1], grad[2]])
+    else:
+        for d in range(3):
+            g.halo_exchange(grad[d])
+    g.synchronize()
+    assert rel_err(grad.cpu().numpy().T, c.dqdx[gi]) <= tol, "nodal gradient"
+
+    # ---- mass flow rate of the edges this rank computes: the oracle's bits
+    mdot = torch.full((ne,), -7.0, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    g.compute_mdot_edges(coords, t(c.dpdx[gi].T), t(c.vel[gi].T), t(c.p[gi]), t(c.rho[gi]), area_d, c.dt, mdot)
+    g.synchronize()
+    mine = (eowner == rank) if export else np.ones(ne, bool)
+    assert np.array_equal(mdot.cpu().numpy()[mine], c.mdot[ge][mine]), "mdot"
+    assert not export or bool((mdot.cpu().numpy()[~mine] == -7.0).all())
+
+    # ---- velocity projection on every local node: the oracle's bits
+    dp_new = po.nodal_grad(c.m.edge_nodes, c.area, c.vol, c.p + 0.25 * c.q)
+    u_ref = po.project_nodal_velocity(c.dt, 1.0, dp_new, c.dpdx, c.rho, c.vel)
+    u = t(c.vel[gi].T)
+    torch.cuda.synchronize()
+    g.project_nodal_velocity(c.dt, 1.0, t(dp_new[gi].T), t(c.dpdx[gi].T), t(c.rho[gi]), u)
+    g.synchronize()
+    assert np.array_equal(u.cpu().numpy().T, u_ref[gi]), "projected velocity"
+
+    # ---- and the assembly that consumes them (export mode on bricks is new; slabs: export_test)
+    g.zeroSystem()
+    g.assemble_continuity_edges(coords, t(c.dpdx[gi].T), t(c.vel[gi].T), t(c.p[gi]), t(c.rho[gi]), area_d, c.dt)
+    g.loadComplete()
+    ls = c.oracle_continuity()
+    rp, ci, v = ls.owned_csr()
+    grp, gci = g.graph()
+    gv, gb = g.matrix_values(), g.rhs()
+    for r in range(nO):
+        G = gi[r]
+        cols = gi[gci[grp[r]:grp[r + 1]]]
+        o = np.argsort(cols)
+        assert np.array_equal(cols[o], ci[rp[G]:rp[G + 1]])
+        ref = v[rp[G]:rp[G + 1]]
+        assert np.abs(gv[grp[r]:grp[r + 1]][o] - ref).max() <= tol * np.abs(ref).max(), r
+    assert rel_err(gb, ls.owned_rhs()[gi[:nO]]) <= tol
+    assert not comm.errors, comm.errors
+    g.close()
+
+
 def main():
     mode = sys.argv[1]
     import datetime
@@ -687,6 +804,8 @@ def main():
         export_test(rank, world)
     elif mode == "config":
         config_test(rank, world, sys.argv[2])
+    elif mode == "adjacent":
+        adjacent_test(rank, world, sys.argv[2])
     elif mode == "baddiag":
         baddiag_test(rank, world)
     elif mode == "loopback":

@@ -83,6 +83,16 @@ def test_native_rccl_callbacks_world_1(method, side_stream):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,kind", [(2, "owner"), (3, "owner"), (2, "export"), (3, "export"), (8, "export_block")])
+def test_adjacent_algorithms_and_parallel_sum_on_several_ranks(nproc, kind):
+    """Hex8 geometry, projected nodal gradient, mass flow rate and velocity projection on 2 / 3 slabs and
+    on 2 x 2 x 2 bricks against the np = 1 oracle on owned, shared and ghost entries: owner-computes
+    (complete owned sums + halo exchange) and the reference's way (own elements / edges + the
+    device-side stk::mesh::parallel_sum, nalu_gpu_parallel_sum), then the assembly that consumes them."""
+    _launch(nproc, "adjacent", kind, timeout=400)
+
+
+@pytest.mark.gpu
 def test_native_rccl_send_recv_loopback_on_a_periodic_box():
     """ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the side stream, the
     event hand-over, the interior / boundary split of the SpMV and exchange_rows all execute on RCCL
