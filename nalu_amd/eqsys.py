@@ -76,13 +76,16 @@ class FixPressureAtNodeAlgorithm(SolverAlgorithm):
     """src/FixPressureAtNodeAlgorithm.C:59-79: reset the row, then sum 1.0 / (pRef - p)."""
 
     def __init__(self, node_lid, ref_pressure, pressure_at_node):
+        """pressure_at_node: a number, or the (device) pressure field itself -- read at execute() like
+        the reference's stk::mesh::field_data(*pressure_, node) (:72)"""
         self.node, self.pref, self.p = node_lid, ref_pressure, pressure_at_node
 
     def execute(self, linsys):
         if self.node is None:  # the node lives on another rank
             return
+        p = self.p if isinstance(self.p, (int, float)) else float(self.p[self.node])
         linsys.resetRows([self.node])
-        linsys.sumInto([self.node], [self.pref - self.p], [1.0])
+        linsys.sumInto([self.node], [self.pref - p], [1.0])
 
 
 class DirichletBC(SolverAlgorithm):
@@ -166,3 +169,100 @@ class EquationSystem:
         if error > 0:
             print(f"Error in {self.name}::solve_and_update()  ")
         return error
+
+
+class ContinuityProjectionLoop:
+    """The continuity half of LowMachEquationSystem::solve_and_update (src/LowMachEquationSystem.C:621-717)
+    with everything device resident: per Picard iteration
+        continuity assemble_and_solve(pTmp)   (:674)
+        pressure += pTmp                      (:678-683, field_axpby)
+        mass_flow_rate = ComputeMdotEdge      (:689)
+        project_nodal_velocity                (:695 -> :772-855: uTmp = dpdx, dpdx = G p, u -= tau/rho (dpdx - uTmp))
+    (the momentum solve between the iterations is out of scope; compute_vrtm is the identity on a
+    fixed mesh).  `eq` is the continuity EquationSystem whose INTERIOR algorithm reads F; F holds the
+    SoA device tensors coords, dpdx, vel, p, rho, area, vol, mdot (nodal ones with n_cols entries: on
+    several ranks the copies are refreshed by the halo exchange after every nodal gradient)."""
+
+    def __init__(self, eq, F, dt, gamma1=1.0, noc=1.0, interp_together=1.0):
+        import torch
+        self.eq, self.g, self.F = eq, eq.linsys, F
+        self.dt, self.gamma1, self.noc, self.interp = dt, gamma1, noc, interp_together
+        self.pTmp = torch.zeros_like(F["p"])
+        self.uTmp = torch.zeros_like(F["dpdx"])
+        self.isInit = True
+        self.timer = dict(assemble_and_solve=0.0, update=0.0, mdot=0.0, project=0.0)
+
+    def compute_projected_nodal_gradient(self):
+        """AssembleNodalGradAlgorithmDriver (src/AssembleNodalGradAlgorithmDriver.C:59-123): dpdx = G p"""
+        g, F = self.g, self.F
+        g.nodal_grad_edges(F["area"], F["vol"], F["p"], F["dpdx"])
+        if g.n_cols > g.n_owned:
+            for d in range(3):
+                g.halo_exchange(F["dpdx"][d])
+
+    def compute_mdot(self):
+        F = self.F
+        self.g.compute_mdot_edges(F["coords"], F["dpdx"], F["vel"], F["p"], F["rho"], F["area"], self.dt, F["mdot"],
+                                  self.gamma1, self.noc, self.interp)
+
+    def project_nodal_velocity(self):
+        """:772-855"""
+        F = self.F
+        self.uTmp.copy_(F["dpdx"])  # (torch copy on the current stream = the library's stream)
+        self.compute_projected_nodal_gradient()
+        self.g.project_nodal_velocity(self.dt, self.gamma1, F["dpdx"], self.uTmp, F["rho"], F["vel"])
+
+    def solve_and_update(self, max_iterations=1, sync=None):
+        import time
+        sync = sync or (lambda: None)
+
+        def lap(name, t0):
+            sync()
+            t1 = time.perf_counter()
+            self.timer[name] += t1 - t0
+            return t1
+        if self.isInit:  # :626-634
+            self.compute_projected_nodal_gradient()
+            self.compute_mdot()
+            self.isInit = False
+        for _ in range(max_iterations):
+            sync()
+            t = time.perf_counter()
+            self.eq.assemble_and_solve(self.pTmp)
+            t = lap("assemble_and_solve", t)
+            self.g.field_axpby(1.0, self.pTmp, 1.0, self.F["p"])
+            t = lap("update", t)
+            self.compute_mdot()
+            t = lap("mdot", t)
+            self.project_nodal_velocity()
+            lap("project", t)
+
+
+class ScalarTransportLoop:
+    """MixtureFractionEquationSystem::solve_and_update (src/MixtureFractionEquationSystem.C:905-937): per
+    iteration assemble_and_solve(zTmp), update_and_clip (:942-1013), compute_projected_nodal_gradient.
+    F: coords, dqdx, vel, q, rho, gamma, area, mdot, vol (SoA device tensors, nodal ones n_cols long)."""
+
+    def __init__(self, eq, F, delta_clip=0.0):
+        import torch
+        self.eq, self.g, self.F, self.delta_clip = eq, eq.linsys, F, delta_clip
+        self.zTmp = torch.zeros_like(F["q"])
+        self.qUF = torch.zeros_like(F["q"])
+        self.isInit = True
+        self.clip_info = None
+
+    def compute_projected_nodal_gradient(self):
+        g, F = self.g, self.F
+        g.nodal_grad_edges(F["area"], F["vol"], F["q"], F["dqdx"])
+        if g.n_cols > g.n_owned:
+            for d in range(3):
+                g.halo_exchange(F["dqdx"][d])
+
+    def solve_and_update(self, max_iterations=1, diagnostics=False):
+        if self.isInit:  # :910-913
+            self.compute_projected_nodal_gradient()
+            self.isInit = False
+        for _ in range(max_iterations):
+            self.eq.assemble_and_solve(self.zTmp)
+            self.clip_info = self.g.update_and_clip(self.zTmp, self.F["q"], self.qUF, self.delta_clip, diagnostics)
+            self.compute_projected_nodal_gradient()

@@ -72,3 +72,51 @@ def rel_err(a, b):
     a, b = np.asarray(a), np.asarray(b)
     den = np.abs(b).max()
     return np.abs(a - b).max() / (den if den > 0 else 1.0)
+
+
+# ---- the composed loops on the oracle (the reference's call order, np = 1) -------------------
+def oracle_continuity_loop(po, c, n_iter, noc=1.0, interp=1.0, **solver_kw):
+    """continuity half of LowMachEquationSystem::solve_and_update (src/LowMachEquationSystem.C:621-717):
+    assemble_and_solve -> p += pTmp -> mdot -> project_nodal_velocity (:772-855), n_iter times"""
+    en, area, vol, xyz, rho = c.m.edge_nodes, c.area, c.vol, c.m.xyz, c.rho
+    p, vel = c.p.copy(), c.vel.copy()
+    dpdx = po.nodal_grad(en, area, vol, p)                                   # isInit (:626-634)
+    mdot = po.compute_mdot(en, area, xyz, dpdx, vel, p, rho, c.dt, 1.0, noc, interp)
+    ls = c.oracle_system()
+    its, hists = [], []
+    for _ in range(n_iter):
+        ls.zero()
+        ls.assemble_continuity(en, area, xyz, dpdx, vel, p, rho, c.dt, 1.0, noc, interp)
+        ls.reset_rows([0])
+        ls.sum_into([0], [0.0 - p[0]], [1.0])
+        r = ls.solve(**solver_kw)
+        its.append(r["iters"])
+        hists.append(r["history"])
+        p = po.field_axpby(1.0, r["x"], 1.0, p)
+        mdot = po.compute_mdot(en, area, xyz, dpdx, vel, p, rho, c.dt, 1.0, noc, interp)
+        uTmp = dpdx
+        dpdx = po.nodal_grad(en, area, vol, p)
+        vel = po.project_nodal_velocity(c.dt, 1.0, dpdx, uTmp, rho, vel)
+    return dict(p=p, vel=vel, dpdx=dpdx, mdot=mdot, iters=its, history=hists)
+
+
+def oracle_scalar_loop(po, c, n_iter, opts, delta_clip=0.0, **solver_kw):
+    """MixtureFractionEquationSystem::solve_and_update (src/MixtureFractionEquationSystem.C:905-937)"""
+    en, area, vol, xyz, rho = c.m.edge_nodes, c.area, c.vol, c.m.xyz, c.rho
+    q, qN = c.q.copy(), 0.9 * c.q
+    dqdx = po.nodal_grad(en, area, vol, q)
+    ls = po.LinSys(1, c.m.nnodes)
+    ls.add_connections(en)
+    ls.add_connections(np.arange(c.m.nnodes, dtype=np.int32).reshape(-1, 1))
+    ls.finalize()
+    its, clips = [], []
+    for _ in range(n_iter):
+        ls.zero()
+        ls.assemble_scalar(en, area, c.mdot, xyz, dqdx, c.vel, q, rho, c.gamma, po.scalar_opts(**opts))
+        ls.assemble_scalar_mass_be(qN, q, rho, rho, vol, c.dt)
+        r = ls.solve(**solver_kw)
+        its.append(r["iters"])
+        q, uf, info = po.update_and_clip(q, r["x"], delta_clip)
+        clips.append(info)
+        dqdx = po.nodal_grad(en, area, vol, q)
+    return dict(q=q, q_unfiltered=uf, dqdx=dqdx, iters=its, clips=clips)

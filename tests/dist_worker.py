@@ -788,6 +788,95 @@ def adjacent_test(rank, world, kind):
     g.close()
 
 
+def picard_test(rank, world):
+    """VERDICT r2 item 4 on several ranks: three iterations of the pressure-projection loop and of the
+    scalar transport loop (nalu_amd.eqsys.ContinuityProjectionLoop / ScalarTransportLoop), fields
+    device resident and changing between the iterations, against the oracle's np = 1 composition on
+    owned, shared and ghost entries."""
+    from oracle import pyoracle as po
+    from common import Case, rel_err, oracle_continuity_loop, oracle_scalar_loop
+    from nalu_amd import eqsys
+    from nalu_amd.comm import TorchComm
+    dims = (9, 8, 19)
+    c = Case(po, 0, 0.125, dims=dims)
+    S = nalu_amd.BoxSlab(*dims, rank, world)
+    gi = S.gids - 1
+    key = c.m.edge_nodes[:, 0].astype(np.int64) * c.m.nnodes + c.m.edge_nodes[:, 1]
+    ge = np.searchsorted(key, gi[S.edge_nodes[:, 0]] * c.m.nnodes + gi[S.edge_nodes[:, 1]])
+    dev = "cuda:0"
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    soa = lambda a: t(a[gi].T)
+
+    def system():
+        g = nalu_amd.GpuLinearSystem(1, 0, torch.cuda.current_stream().cuda_stream)
+        g.beginLinearSystemConstruction(S.n_owned, S.n_shared, S.n_ghost, S.gids, S.owners, rank)
+        return g
+
+    def connect(g):
+        g.set_halo_plan(S.neighbors, S.send_offsets, S.send_lids, S.recv_offsets)
+        return TorchComm(g, S.neighbors, S.send_offsets, S.recv_offsets, dev)
+
+    def fields():
+        return dict(coords=soa(c.m.xyz), dpdx=soa(c.dpdx), dqdx=soa(c.dqdx), vel=soa(c.vel), p=t(c.p[gi]), q=t(c.q[gi]),
+                    rho=t(c.rho[gi]), gamma=t(c.gamma[gi]), area=t(c.area[ge].T), mdot=t(c.mdot[ge]), vol=t(c.vol[gi]))
+
+    # ---- pressure projection
+    kw = dict(method="cg", preconditioner="jacobi", tolerance=1e-12, max_iterations=600, kspace=50)
+    okw = {"precond" if k == "preconditioner" else k: v for k, v in kw.items()}
+    ref = oracle_continuity_loop(po, c, 3, **okw)
+    F = fields()
+    g = system()
+    eq = eqsys.EquationSystem(g, nalu_amd.LinearSolverConfig(**kw), "ContinuityEQS")
+    eq.solverAlgDriver.solverAlgMap["INTERIOR"] = eqsys.AssembleContinuityEdgeSolverAlgorithm(S.edge_nodes, F, c.dt)
+    eq.solverAlgDriver.solverAlgMap["REF_PRESSURE"] = eqsys.FixPressureAtNodeAlgorithm(0 if rank == 0 else None, 0.0, F["p"])
+    eq.initialize()
+    comm = connect(g)
+    torch.cuda.synchronize()
+    loop = eqsys.ContinuityProjectionLoop(eq, F, c.dt)
+    its = []
+    for _ in range(3):
+        loop.solve_and_update(1)
+        its.append(g.linearSolveIterations)
+    g.synchronize()
+    assert not comm.errors, comm.errors
+    assert all(abs(a - b) <= 1 for a, b in zip(its, ref["iters"])), (its, ref["iters"])
+    for name, got, want in (("p", F["p"], ref["p"][gi]), ("vel", F["vel"].T, ref["vel"][gi]),
+                            ("dpdx", F["dpdx"].T, ref["dpdx"][gi]), ("mdot", F["mdot"], ref["mdot"][ge])):
+        assert rel_err(got.cpu().numpy(), want) <= 1e-10, (name, rel_err(got.cpu().numpy(), want))
+    g.close()
+
+    # ---- scalar transport with update_and_clip
+    opts = dict(alpha_upw=1.0, upw_factor=1.0, hybrid_factor=1.0, limiter=True)
+    kw = dict(method="gmres", preconditioner="jacobi", tolerance=1e-12, max_iterations=300, kspace=50)
+    okw = {"precond" if k == "preconditioner" else k: v for k, v in kw.items()}
+    ref = oracle_scalar_loop(po, c, 3, opts, delta_clip=0.05, **okw)
+    F = fields()
+    g = system()
+    eq = eqsys.EquationSystem(g, nalu_amd.LinearSolverConfig(**kw), "MixtureFractionEQS")
+    eq.solverAlgDriver.solverAlgMap["INTERIOR"] = eqsys.AssembleScalarEdgeSolverAlgorithm(S.edge_nodes, F, **opts)
+    eq.solverAlgDriver.solverAlgMap["MASS"] = eqsys.ScalarMassBackwardEulerAlgorithm(
+        np.arange(S.n_owned, dtype=np.int32), 0.9 * F["q"], F["q"], F["rho"], F["rho"], F["vol"], c.dt)
+    eq.initialize()
+    comm = connect(g)
+    torch.cuda.synchronize()
+    loop = eqsys.ScalarTransportLoop(eq, F, delta_clip=0.05)
+    clipped = torch.zeros(2, dtype=torch.float64)
+    for k in range(3):
+        loop.solve_and_update(1, diagnostics=True)
+    # the clip counts of the last iteration over the OWNED nodes, summed over the ranks (the reference
+    # counts owned + shared per rank, :955-957; the oracle has one rank)
+    qo = loop.qUF[:S.n_owned].cpu().numpy()
+    clipped[0], clipped[1] = float((qo < -0.05).sum()), float((qo > 1.05).sum())
+    dist.all_reduce(clipped)
+    assert clipped[0].item() == ref["clips"][-1][0] and clipped[1].item() == ref["clips"][-1][1]
+    assert loop.clip_info[0] >= (qo < -0.05).sum()  # (this rank's count includes its shared / ghost copies)
+    g.synchronize()
+    assert not comm.errors, comm.errors
+    assert rel_err(F["q"].cpu().numpy(), ref["q"][gi]) <= 1e-10
+    assert rel_err(F["dqdx"].T.cpu().numpy(), ref["dqdx"][gi]) <= 1e-10
+    g.close()
+
+
 def main():
     mode = sys.argv[1]
     import datetime
@@ -806,6 +895,8 @@ def main():
         config_test(rank, world, sys.argv[2])
     elif mode == "adjacent":
         adjacent_test(rank, world, sys.argv[2])
+    elif mode == "picard":
+        picard_test(rank, world)
     elif mode == "baddiag":
         baddiag_test(rank, world)
     elif mode == "loopback":

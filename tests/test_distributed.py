@@ -93,6 +93,14 @@ def test_adjacent_algorithms_and_parallel_sum_on_several_ranks(nproc, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_composed_picard_loops_on_several_ranks(nproc):
+    """three iterations of the pressure-projection loop and of the scalar transport loop with update_and_clip
+    on 2 / 3 ranks, device resident, against the oracle's np = 1 composition (fields <= 1e-10)"""
+    _launch(nproc, "picard", timeout=400)
+
+
+@pytest.mark.gpu
 def test_native_rccl_send_recv_loopback_on_a_periodic_box():
     """ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the side stream, the
     event hand-over, the interior / boundary split of the SpMV and exchange_rows all execute on RCCL
