@@ -221,7 +221,9 @@ def config_test(rank, world, kind):
     tests/test_gpu_bench_path.py establishes at 64^3 / 96^3."""
     sys.path.insert(0, os.path.join(HERE, ".."))
     from bench import RankSystem, workload_dims
-    dims = workload_dims(256, world, "weak") if kind == "weak512" else (256, 256, 256)
+    # full512: BASELINE config 5 as a whole -- the 512^3 box (134 M nodes) on 8 ranks, 16.8 M nodes each
+    dims = workload_dims(256, world, "weak") if kind in ("weak512", "full512") else (256, 256, 256)
+    assert kind != "full512" or (world == 8 and dims == (512, 512, 512))
     cfg = nalu_amd.LinearSolverConfig(method="cg", preconditioner="jacobi", tolerance=1e-5, max_iterations=50)
     if kind == "scalar256":  # config 4: scalar transport (upwind, limiter) + mass term, GMRES(50)/Jacobi
         cfg = nalu_amd.LinearSolverConfig(method="gmres", preconditioner="jacobi", tolerance=1e-5,

@@ -129,6 +129,16 @@ def test_baseline_configs_3_4_5_two_ranks_on_one_gpu(kind):
 
 
 @pytest.mark.gpu
+def test_baseline_config_5_full_size_eight_ranks_on_one_gpu():
+    """BASELINE config 5 at its own size: the 512^3 box (134 M nodes, 402 M edges) on
+    EIGHT ranks -- 16.8 M nodes each, 512^2 halo faces, through bench.RankSystem -- sharing the one GPU over
+    gloo, against the single-rank run of the whole 512^3 box on the same GPU: iteration count, residual
+    history (<= 1e-10), residual norms, matrix / rhs / solution sums.  (Its own time guard: the host builds
+    1.1 G mesh entities for the two runs.)"""
+    _launch(8, "config", "full512", timeout=1100)
+
+
+@pytest.mark.gpu
 def test_bench_multirank_path_rehearsal():
     """bench.py --gpus 2 as the driver launches it, but with two ranks on the one GPU of the
     test box over gloo (NALU_BENCH_BACKEND): partition, halo plan, callbacks, barrier / MAX
