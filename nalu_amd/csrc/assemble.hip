@@ -749,6 +749,256 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_march(SellView A, t
   }
 }
 
+// Lagged marching row gather, barrier-free (round 3; the default where every run qualifies, NG_ASM_LAG=0/1):
+// the same runs of slices as k_assemble_rows_march, the same fluxes and the same summation order per row,
+// bit for bit -- but arranged so that ALL users of a nodal line ask for it in the SAME step, and without
+// LDS or barriers:
+//  * a step loads its OWN row together with the rows' y neighbours (far slots 1, 4); the row below is
+//    the previous step's own row, kept in registers.  The run next door loads this line as its far
+//    neighbour in the very same step (runs of adjacent lines are dispatched together and advance in
+//    step), so the 4 MiB L2 serves two of the three requests: the marching kernel asked for its next
+//    own row one step AHEAD, and a step of an XCD's resident workgroups moves more bytes than its L2
+//    holds (5.5 GB of traffic per launch at 256^3 against 4.2 GB compulsory).
+//  * the edge between two consecutive rows is evaluated by the UPPER row (slot 0, with the lower row
+//    from registers); the lower row's shares of it -- lhs[3], lhs[2], rhs[1], bit for bit what its own
+//    evaluation of slot 5 gives (mirror invariance) -- complete that row one step late: its last edge
+//    is also the last addition of its CSR-ordered sums, so nothing is reordered.
+//  * the in-slice neighbours (near slots 2, 3: the rows next door, k_march_links checks it) come from
+//    the neighbouring LANES by full-wave DPP shifts; a wave's first / last lane loads its neighbour in
+//    the next wave itself (one two-lane load per field).  No LDS, no barrier: the four waves of a
+//    workgroup run free.
+//  * edge ids advance by a per-slot constant per step (MarchSeg::eStep for the regular rows, ::xStep for
+//    every wave's irregular row; runs are cut where the constants change): no tag loads.
+// Per row and step: 56-59 eight-byte load instructions (11 of them two lanes wide) against 48 + 5 tag
+// loads, no LDS traffic, no barrier.  HBM traffic at 256^3: 4.87 GB per launch (1.17 x algorithmic) against
+// 5.54 GB; time: continuity 1.00 -> 0.975 ms, scalar 1.40 (row kernel) -> 1.25 ms.  What bounds it now
+// (profiles/r3_lag_ablation.txt): without the flux arithmetic 0.96 ms, without the y gathers (L2 hits)
+// 0.875, without the stores 0.82: the kernel sits ~15 % above the mixed read / write HBM roof of its bytes.
+// kDppArea: the area vector of the edge to the lane below is that lane's edge to the lane above, shifted in
+// instead of loaded (continuity: 1.016 -> 0.985 ms at 256^3; the scalar operator's 4-double edges then spill:
+// 1.26 -> 1.37 ms); stores are nontemporal for both (-1.5 %: the written lines are not read again)
+template <class Op> struct LagCfg { static constexpr bool kDefault = true, kDppArea = true; };
+template <> struct LagCfg<ScalOp> { static constexpr bool kDefault = true, kDppArea = false; };
+// (development aids: ablations of the lagged kernel, never built into the shipped library)
+#ifdef NG_LAG_NOFLUX
+template <class Op>
+__device__ __forceinline__ void lag_fake_edge(const typename Op::Params &, const typename Op::Edge &E,
+                                              const typename Op::Node &L, const typename Op::Node &R, double lhs[4],
+                                              double rh[2])
+{
+  const double *pe = reinterpret_cast<const double *>(&E), *pl = reinterpret_cast<const double *>(&L),
+               *pr = reinterpret_cast<const double *>(&R);
+  double s = 0.0;
+  for (int f = 0; f < (int)(sizeof(typename Op::Edge) / 8); ++f) s += pe[f];
+  for (int f = 0; f < (int)(sizeof(typename Op::Node) / 8); ++f) s += pl[f] + pr[f];
+  lhs[0] = s; lhs[1] = -s; lhs[2] = s + 1.0; lhs[3] = s - 1.0; rh[0] = s * 0.5; rh[1] = -s * 0.5;
+}
+#define LAG_EDGE(...) lag_fake_edge<Op>(__VA_ARGS__)
+#else
+#define LAG_EDGE(...) Op::edge(__VA_ARGS__)
+#endif
+#if defined(NG_LAG_NOSTORE)
+#define LAG_ST(p, v) do { if ((v) == 1.2345e300) *(p) = (v); } while (0)
+#else
+#define LAG_ST(p, v) __builtin_nontemporal_store((v), (p))
+#endif
+
+__device__ __forceinline__ double dpp_from_lower_lane(double v, double lane0)
+{  // lane i gets lane i - 1's v; lane 0 keeps lane0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(lane0), lo, 0x138, 0xF, 0xF, false);  // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0), hi, 0x138, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_upper_lane(double v, double lane63)
+{  // lane i gets lane i + 1's v; lane 63 keeps lane63
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(lane63), lo, 0x130, 0xF, 0xF, false);  // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(lane63), hi, 0x130, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <class Op, bool SET>
+__global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lag(SellView A, typename Op::Params P,
+                                                                double *__restrict__ rhs)
+{
+  using Node = typename Op::Node;
+  using Edge = typename Op::Edge;
+  constexpr int NF = sizeof(Node) / sizeof(double);
+  constexpr int NE = BURST_NE;
+  const MarchSeg &G = A.march[xcd_run(blockIdx.x, A.nMarchPat, A.marchXcdRun)];
+  const int r = threadIdx.x, lane = r & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(r >> 6);
+  const int gStart = G.start, gLen = G.len, gRowStep = G.rowStep;
+  const long long gOffStep = G.offStep;
+  int row = gStart * SELL_C + r;  // (pattern slices are full: every row is a row of the matrix)
+  const BurstSlice *const S = A.burst + gStart;
+  const BurstRow D = S->reg, X = S->irr[wv];
+  const int w = S->w;
+  const unsigned long long mI = S->irrMask[wv];
+  long long pos0 = S->off + r;
+  const bool irregular = (mI >> lane) & 1ULL;  // the wave's one irregular row
+  unsigned eStep[NE];  // what the lane's edge ids advance by per step (slot 5's id is only needed after the last one)
+#pragma unroll
+  for (int q = 0; q < NE; ++q) eStep[q] = irregular ? G.xStep[wv][q] : G.eStep[q];
+  const unsigned eLast5 = eStep[NE - 1] * (unsigned)(gLen - 1);
+  // its edges, moved to the slots of the regular offsets they have (wave-uniform arithmetic)
+  unsigned xe[NE], xk[NE], xact = 0;
+  {
+    const int rowX = gStart * SELL_C + wv * 64 + (int)(X.lane & 63u), nx = (int)(X.info & 15u);
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      xe[q] = 0;
+      xk[q] = 0;
+#pragma unroll
+      for (int e = 0; e < NE; ++e)
+        if (e < nx && X.ko[e] - rowX == D.ko[q]) {
+          xe[q] = X.tb[e];
+          xk[q] = (X.kl >> (4 * e)) & 15u;
+          xact |= 1u << q;
+        }
+    }
+  }
+  unsigned eid[NE], kkAll = 0;  // (the entry indices of the six slots, four bits each: registers are what is scarce)
+#pragma unroll
+  for (int q = 0; q < NE; ++q) {
+    eid[q] = irregular ? xe[q] : D.tb[q] + (unsigned)row;
+    kkAll |= (irregular ? xk[q] : (D.kl >> (4 * q)) & 15u) << (4 * q);
+  }
+  auto kk = [&](int q) { return (long long)((kkAll >> (4 * q)) & 15u); };
+  const unsigned act = irregular ? xact : (1u << NE) - 1u;
+  const unsigned info = irregular ? X.info : D.info;
+  const int kDiag = (int)((info >> 4) & 15u) - 1;
+  const unsigned zeroMask = (info >> 8) & 255u;
+  // the lanes at the ends of the wave take their in-slice neighbour in the next wave from memory
+  const bool endLane = (lane == 0 && (act & 4u)) || (lane == 63 && (act & 8u));
+  const int endOff = lane == 0 ? -1 : 1;
+  Node prev;       // the row below: the previous step's own row (first step: loaded)
+  double pDiag = 0.0, pRhs = 0.0;  // its sums, complete but for its last edge
+  if (act & 1u) prev = Op::load(P, row + D.ko[0]);
+  for (int t = 0; t < gLen; ++t) {
+    // ---- every load of the step at once
+    Node own = Op::load(P, row);
+    Edge E[NE - 1];
+    Node ym, yp, en;
+#pragma unroll
+    for (int e = 0; e < NE - 1; ++e) {
+      if (LagCfg<Op>::kDppArea && e == 2) continue;  // (the edge to the lane below is that lane's edge to the lane above)
+      if ((act >> e) & 1u) E[e] = Op::load_edge(P, (long long)(eid[e] & 0x7FFFFFFFu));
+    }
+    if (LagCfg<Op>::kDppArea) {
+      // the edge to the lane below is that lane's edge to the lane above: shifted, not loaded (the wave's
+      // first lane loads it)
+      Edge e0;
+      if (lane == 0 && (act & 4u)) e0 = Op::load_edge(P, (long long)(eid[2] & 0x7FFFFFFFu));
+      const double *ps = reinterpret_cast<const double *>(&E[3]), *p0 = reinterpret_cast<const double *>(&e0);
+      double *pd = reinterpret_cast<double *>(&E[2]);
+#pragma unroll
+      for (int f = 0; f < (int)(sizeof(Edge) / sizeof(double)); ++f) pd[f] = dpp_from_lower_lane(ps[f], p0[f]);
+    }
+#ifdef NG_LAG_NOY
+    ym = own;
+    yp = own;
+#else
+    if (act & 2u) ym = Op::load(P, row + D.ko[1]);
+    if (act & 16u) yp = Op::load(P, row + D.ko[4]);
+#endif
+    if (endLane) en = Op::load(P, row + endOff);
+    double diag = 0.0, b = 0.0;
+    double lhs[4], rh[2];
+    // slot 0: the edge to the row below; its other half completes that row
+    if (act & 1u) {
+      LAG_EDGE(P, Op::mirrored(E[0], (eid[0] >> 31) != 0), own, prev, lhs, rh);
+      diag += lhs[0];
+      b += rh[0];
+      const long long pos = pos0 + kk(0) * SELL_C;
+      if (SET) LAG_ST(A.vals + pos, lhs[1]);
+      else A.vals[pos] += lhs[1];
+    }
+    if (t > 0) {
+      const long long posP = pos0 - gOffStep;
+      if (act & 32u) {
+        pDiag += lhs[3];
+        pRhs += rh[1];
+        const long long pos = posP + kk(NE - 1) * SELL_C;
+        if (SET) LAG_ST(A.vals + pos, lhs[2]);
+        else A.vals[pos] += lhs[2];
+      }
+      if (kDiag >= 0) {
+        const long long pos = posP + (long long)kDiag * SELL_C;
+        if (SET) LAG_ST(A.vals + pos, pDiag);
+        else A.vals[pos] += pDiag;
+      }
+      if (SET) LAG_ST(rhs + row - gRowStep, pRhs);
+      else rhs[row - gRowStep] += pRhs;
+    }
+    // slots 1 .. 4 in CSR order.  The rows next door (slots 2, 3) come out of the neighbouring lanes by
+    // full-wave DPP shifts, formed right before their use and outside the per-lane conditions (every lane
+    // takes part in a shift); the lanes at the ends of the wave keep what they loaded themselves.
+    auto slot = [&](int e, const Node &nb) {
+      if ((act >> e) & 1u) {
+        LAG_EDGE(P, Op::mirrored(E[e], (eid[e] >> 31) != 0), own, nb, lhs, rh);
+        diag += lhs[0];
+        b += rh[0];
+        const long long pos = pos0 + kk(e) * SELL_C;
+        if (SET) LAG_ST(A.vals + pos, lhs[1]);
+        else A.vals[pos] += lhs[1];
+      }
+    };
+    slot(1, ym);
+    {
+      Node xm;
+      const double *po = reinterpret_cast<const double *>(&own), *pe = reinterpret_cast<const double *>(&en);
+      double *pm = reinterpret_cast<double *>(&xm);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) pm[f] = dpp_from_lower_lane(po[f], pe[f]);
+      slot(2, xm);
+    }
+    {
+      Node xp;
+      const double *po = reinterpret_cast<const double *>(&own), *pe = reinterpret_cast<const double *>(&en);
+      double *pp = reinterpret_cast<double *>(&xp);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) pp[f] = dpp_from_upper_lane(po[f], pe[f]);
+      slot(3, xp);
+    }
+    slot(4, yp);
+    if (SET) {
+      for (int k = 0; k < w; ++k)
+        if ((zeroMask >> k) & 1u) A.vals[pos0 + (long long)k * SELL_C] = 0.0;
+    }
+    // ---- step
+    prev = own;
+    pDiag = diag;
+    pRhs = b;
+    if (t + 1 < gLen) {
+#pragma unroll
+      for (int q = 0; q < NE - 1; ++q) eid[q] += eStep[q];
+      row += gRowStep;
+      pos0 += gOffStep;
+    }
+  }
+  // ---- the last row of the run: its edge to the row above
+  if (act & 32u) {
+    double lhs[4], rh[2];
+    eid[NE - 1] += eLast5;
+    LAG_EDGE(P, Op::mirrored(Op::load_edge(P, (long long)(eid[NE - 1] & 0x7FFFFFFFu)), (eid[NE - 1] >> 31) != 0), prev,
+             Op::load(P, row + D.ko[NE - 1]), lhs, rh);
+    pDiag += lhs[0];
+    pRhs += rh[0];
+    const long long pos = pos0 + kk(NE - 1) * SELL_C;
+    if (SET) LAG_ST(A.vals + pos, lhs[1]);
+    else A.vals[pos] += lhs[1];
+  }
+  if (kDiag >= 0) {
+    const long long pos = pos0 + (long long)kDiag * SELL_C;
+    if (SET) LAG_ST(A.vals + pos, pDiag);
+    else A.vals[pos] += pDiag;
+  }
+  if (SET) LAG_ST(rhs + row, pRhs);
+  else rhs[row] += pRhs;
+}
+
 // Entry-parallel row gather, persistent: a workgroup of NW waves assembles one QUARTER slice
 // (64 rows) per iteration; wave k evaluates the k-th entry of those 64 rows (for w > NW:
 // entries k, k + NW, ...), so the loads of a row's edges -- edge data and out-of-quarter
@@ -954,10 +1204,14 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
       int grid = std::max(1, perCu) * std::max(1, cus);
       grid = std::min((grid + 7) / 8 * 8, (nQ + 7) / 8 * 8);
       kern<<<grid, QROWS * 8, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
-    } else if ((h->asmVariant == 4 || (MarchCfg<Op>::kDefault && march_by_default(h))) && h->dBurst && h->dMarch &&
-               !h->dEdgeOwned) {
+    } else if ((h->asmVariant == 4 || ((MarchCfg<Op>::kDefault || (LagCfg<Op>::kDefault && lag_kernel(h))) &&
+                                       march_by_default(h))) &&
+               h->dBurst && h->dMarch && !h->dEdgeOwned) {
       const int nPat = h->nMarchPat, nRest = h->nMarch - h->nMarchPat;
-      if (nPat > 0) {
+      if (nPat > 0 && lag_kernel(h)) {
+        if (set) k_assemble_rows_lag<Op, true><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+        else k_assemble_rows_lag<Op, false><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+      } else if (nPat > 0) {
         if (set) k_assemble_rows_march<Op, true><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
         else k_assemble_rows_march<Op, false><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
       }

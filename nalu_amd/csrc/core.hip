@@ -579,15 +579,20 @@ __device__ int march_pattern(const BurstSlice &a, int s, int nRows)
   return code;
 }
 
-__global__ void k_march_links(int nSlices, int nRows, const BurstSlice *B, int *next, long long *offStep, int *pat)
+__global__ void k_march_links(int nSlices, int nRows, const BurstSlice *B, int *next, long long *offStep, int *pat,
+                              unsigned *eStep, int *lagOk)
 {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nSlices) return;
   next[s] = -1;
   offStep[s] = 0;
+  lagOk[s] = 0;
+  for (int q = 0; q < 5 * BURST_NE; ++q) eStep[(size_t)s * 5 * BURST_NE + q] = 0u;
   const BurstSlice &a = B[s];
   pat[s] = march_pattern(a, s, nRows);
   if (!pat[s]) return;
+  // the lagged kernel takes its in-slice neighbours from the lanes next door
+  lagOk[s] = a.reg.ko[2] == -1 && a.reg.ko[3] == 1;
   const int ne = BURST_NE;
   const int D = a.reg.ko[ne - 1];
   if (D <= 0 || D % SELL_C) return;
@@ -608,6 +613,19 @@ __global__ void k_march_links(int nSlices, int nRows, const BurstSlice *B, int *
   }
   next[s] = (int)sn;
   offStep[s] = b.off - a.off;
+  // edge ids one slice further on (the lagged kernel steps them instead of loading tags): regular rows
+  // have tag = tb + row, so the step is tb' + (row + D) - (tb + row); a wave's irregular row steps by the
+  // difference of its listed tags, kept per slot its edges sit in.  [s][0][q]: regular, [s][1 + wave][q]
+  unsigned *es = eStep + (size_t)s * 5 * BURST_NE;
+  for (int q = 0; q < BURST_NE; ++q) es[q] = b.reg.tb[q] - a.reg.tb[q] + (unsigned)D;
+  for (int wv = 0; wv < 4; ++wv) {
+    const BurstRow &x = a.irr[wv], &y = b.irr[wv];
+    if (x.lane >= 64u) continue;
+    const int rowA = s * SELL_C + wv * 64 + (int)x.lane, nx = (int)(x.info & 15u);
+    for (int e = 0; e < nx && e < BURST_NE; ++e)
+      for (int q = 0; q < BURST_NE; ++q)
+        if (x.ko[e] - rowA == a.reg.ko[q]) es[(1 + wv) * BURST_NE + q] = y.tb[e] - x.tb[e];
+  }
 }
 
 // Tag-offset compression (the assembly kernels' counterpart of the column offsets, see
@@ -947,28 +965,41 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
     // runs of slices for the marching kernel: follow the links while step and storage stride stay
     // the same, at most MARCH_MAX_LEN slices per run; every slice is in exactly one run
     {
-      int *dNext = nullptr, *dPat = nullptr;
+      int *dNext = nullptr, *dPat = nullptr, *dLag = nullptr;
       long long *dOffStep = nullptr;
+      unsigned *dEStep = nullptr;
       NG_HIP(hipMalloc(&dNext, sizeof(int) * (size_t)h->nSlices));
       NG_HIP(hipMalloc(&dPat, sizeof(int) * (size_t)h->nSlices));
+      NG_HIP(hipMalloc(&dLag, sizeof(int) * (size_t)h->nSlices));
       NG_HIP(hipMalloc(&dOffStep, sizeof(long long) * (size_t)h->nSlices));
-      k_march_links<<<(h->nSlices + 255) / 256, 256, 0, h->stream>>>(h->nSlices, nO, h->dBurst, dNext, dOffStep, dPat);
+      NG_HIP(hipMalloc(&dEStep, sizeof(unsigned) * (size_t)h->nSlices * 5 * BURST_NE));
+      k_march_links<<<(h->nSlices + 255) / 256, 256, 0, h->stream>>>(h->nSlices, nO, h->dBurst, dNext, dOffStep, dPat,
+                                                                      dEStep, dLag);
       NG_HIP(hipGetLastError());
-      std::vector<int> nxt((size_t)h->nSlices), pat((size_t)h->nSlices);
+      std::vector<int> nxt((size_t)h->nSlices), pat((size_t)h->nSlices), lagv((size_t)h->nSlices);
       std::vector<long long> ost((size_t)h->nSlices);
+      std::vector<unsigned> est((size_t)h->nSlices * 5 * BURST_NE);
       NG_HIP(hipStreamSynchronize(h->stream));
       NG_HIP(hipMemcpy(nxt.data(), dNext, sizeof(int) * nxt.size(), hipMemcpyDeviceToHost));
       NG_HIP(hipMemcpy(pat.data(), dPat, sizeof(int) * pat.size(), hipMemcpyDeviceToHost));
+      NG_HIP(hipMemcpy(lagv.data(), dLag, sizeof(int) * lagv.size(), hipMemcpyDeviceToHost));
       NG_HIP(hipMemcpy(ost.data(), dOffStep, sizeof(long long) * ost.size(), hipMemcpyDeviceToHost));
+      NG_HIP(hipMemcpy(est.data(), dEStep, sizeof(unsigned) * est.size(), hipMemcpyDeviceToHost));
       (void)hipFree(dNext);
       (void)hipFree(dPat);
+      (void)hipFree(dLag);
       (void)hipFree(dOffStep);
+      (void)hipFree(dEStep);
       const int maxLen = getenv("NG_MARCH_LEN") ? std::max(1, atoi(getenv("NG_MARCH_LEN"))) : MARCH_MAX_LEN;
       std::vector<MarchSeg> segs, others;
       std::vector<char> seen((size_t)h->nSlices, 0);
       for (int s0 = 0; s0 < h->nSlices; ++s0) {
         if (seen[(size_t)s0]) continue;
-        MarchSeg g{s0, 1, 0, 0, 0, pat[(size_t)s0] >> 1, 0};
+        MarchSeg g{};
+        g.start = s0;
+        g.len = 1;
+        g.halo = pat[(size_t)s0] >> 1;
+        g.lag = lagv[(size_t)s0];
         seen[(size_t)s0] = 1;
         if (!pat[(size_t)s0]) {  // not the marching pattern: a run of one slice for the general kernel
           others.push_back(g);
@@ -979,7 +1010,17 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
           const int n1 = nxt[(size_t)cur];
           if (n1 < 0 || seen[(size_t)n1]) break;
           const int step = n1 - cur;
+          const unsigned *es = &est[(size_t)cur * 5 * BURST_NE];
           if (g.len > 1 && (step != g.step || ost[(size_t)cur] != g.offStep)) break;
+          // (a change of the edge-id steps only ends a run that is still fit for the lagged kernel)
+          if (g.len > 1 && g.lag && lagv[(size_t)cur] &&
+              (memcmp(es, g.eStep, sizeof(g.eStep)) != 0 || memcmp(es + BURST_NE, g.xStep, sizeof(g.xStep)) != 0))
+            break;
+          if (g.len == 1) {
+            memcpy(g.eStep, es, sizeof(g.eStep));
+            memcpy(g.xStep, es + BURST_NE, sizeof(g.xStep));
+          }
+          g.lag = g.lag && lagv[(size_t)cur] && lagv[(size_t)n1];
           g.step = step;
           g.rowStep = step * SELL_C;
           g.offStep = ost[(size_t)cur];
@@ -993,9 +1034,11 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
       if (const char *e = getenv("NG_MARCH_XCD")) h->marchXcdRun = std::max(1, atoi(e));
       h->marchSlices = 0;
       h->marchLongest = 0;
+      h->marchLag = !segs.empty();
       for (const MarchSeg &g : segs) {
         h->marchSlices += g.len;
         h->marchLongest = std::max(h->marchLongest, g.len);
+        h->marchLag = h->marchLag && g.lag;
       }
       segs.insert(segs.end(), others.begin(), others.end());
       h->nMarch = (int)segs.size();
@@ -1107,7 +1150,7 @@ extern "C" int nalu_gpu_get_layout_info(nalu_gpu_linsys *h, nalu_gpu_layout_info
   info->max_slice_width = h->maxSliceWidth;
   info->rows_computed_columns = cc;
   info->rows_computed_tags = ct;
-  info->assembly_variant = march_by_default(h) ? 4 : h->asmVariant;
+  info->assembly_variant = (march_by_default(h) || h->asmVariant == 4) ? (lag_kernel(h) ? 5 : 4) : h->asmVariant;
   info->march_runs = h->nMarchPat;
   info->march_slices = h->marchSlices;
   info->march_longest = h->marchLongest;

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -63,8 +64,14 @@ static_assert(sizeof(BurstRow) == 64 && sizeof(BurstSlice) == 384, "burst descri
 struct MarchSeg {
   int start, len, step, rowStep;
   long long offStep;
-  int halo, pad;  // bit 0 / 1: some row reads the node just below / above the slice through a near slot
+  int halo, lag;  // halo bit 0 / 1: some row reads the node just below / above the slice through a near slot;
+                  // lag: the run qualifies for k_assemble_rows_lag (near slots = the lanes next door, eStep valid)
+  unsigned eStep[6];  // edge id (tag) of slot q one slice further on = this slice's + eStep[q] (regular rows)
+  int pad2[2];
+  unsigned xStep[4][6];  // the same for every wave's one irregular row (its edges in the slots they sit in)
+  int pad3[8];
 };
+static_assert(sizeof(MarchSeg) == 192, "march run layout");
 constexpr int MARCH_MAX_LEN = 16;
 // the slot pattern the marching kernel is specialised for (a slice qualifies when, for every row,
 // the neighbours of the slots in MARCH_NEAR are rows of the slice and those of the other slots are
@@ -213,6 +220,7 @@ struct nalu_gpu_linsys {
   long long marchSlices = 0;             // slices in the nMarchPat pattern runs
   int marchLongest = 0;
   int marchXcdRun = 8;
+  bool marchLag = false;  // every pattern run qualifies for the lagged, barrier-free marching kernel
   bool asmExplicit = false;              // an NG_ASM_* variable chose the assembly kernel   // nSlices (null: maxSliceWidth > BURST_W)
 
   // edges
@@ -431,6 +439,15 @@ inline bool march_by_default(const nalu_gpu_linsys *h)
 {
   return !h->asmExplicit && h->asmVariant == 0 && h->dBurst && h->dMarch && !h->dEdgeOwned &&
          2 * h->marchSlices >= (long long)h->nSlices && h->marchSlices >= 4LL * h->nMarchPat;
+}
+
+// the lagged, barrier-free marching kernel runs where every pattern run qualifies (NG_ASM_LAG=0 / 1 forces it
+// off / on -- on only where it applies)
+inline bool lag_kernel(const nalu_gpu_linsys *h)
+{
+  if (!h->marchLag) return false;
+  const char *e = getenv("NG_ASM_LAG");
+  return !(e && atoi(e) == 0);
 }
 
 void timer_begin(nalu_gpu_linsys *h, int which);
