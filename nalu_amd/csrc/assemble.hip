@@ -818,34 +818,44 @@ __device__ __forceinline__ double dpp_from_upper_lane(double v, double lane63)
   return __hiloint2double(hi, lo);
 }
 
-template <class Op, bool SET>
+// GY = 1: a workgroup = the four 64-row waves of one run (list: the runs to take, or null = all pattern runs).
+// GY = 4: a workgroup = the same 64-row quarter of FOUR runs of adjacent lines (list: 4 run indices per
+// group, item = 4 * group + quarter): wave v walks line v of the group, every wave leaves its own row in LDS
+// (double-buffered, one barrier per step, placed where every wave waits for its loads anyway) and takes
+// the far neighbours that are lines of the group from there: 2 far gathers per 4 lines instead of 8.
+template <class Op, bool SET, int GY>
 __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lag(SellView A, typename Op::Params P,
-                                                                double *__restrict__ rhs)
+                                                                double *__restrict__ rhs,
+                                                                const int *__restrict__ list, int nItems)
 {
   using Node = typename Op::Node;
   using Edge = typename Op::Edge;
   constexpr int NF = sizeof(Node) / sizeof(double);
   constexpr int NE = BURST_NE;
-  const MarchSeg &G = A.march[xcd_run(blockIdx.x, A.nMarchPat, A.marchXcdRun)];
+  __shared__ double ldsY[GY > 1 ? 2 * GY * NF * 64 : 1];
   const int r = threadIdx.x, lane = r & 63;
   const int wv = __builtin_amdgcn_readfirstlane(r >> 6);
+  const int item = xcd_run(blockIdx.x, nItems, GY > 1 ? A.marchXcdRun * GY : A.marchXcdRun);
+  // xw: which 64-row quarter of its slices the wave walks
+  const int xw = GY > 1 ? (item & (GY - 1)) : wv;
+  const MarchSeg &G = A.march[GY > 1 ? list[(item & ~(GY - 1)) + wv] : (list ? list[item] : item)];
   const int gStart = G.start, gLen = G.len, gRowStep = G.rowStep;
   const long long gOffStep = G.offStep;
-  int row = gStart * SELL_C + r;  // (pattern slices are full: every row is a row of the matrix)
+  int row = gStart * SELL_C + xw * 64 + lane;  // (pattern slices are full: every row is a row of the matrix)
   const BurstSlice *const S = A.burst + gStart;
-  const BurstRow D = S->reg, X = S->irr[wv];
+  const BurstRow D = S->reg, X = S->irr[xw];
   const int w = S->w;
-  const unsigned long long mI = S->irrMask[wv];
-  long long pos0 = S->off + r;
+  const unsigned long long mI = S->irrMask[xw];
+  long long pos0 = S->off + xw * 64 + lane;
   const bool irregular = (mI >> lane) & 1ULL;  // the wave's one irregular row
   unsigned eStep[NE];  // what the lane's edge ids advance by per step (slot 5's id is only needed after the last one)
 #pragma unroll
-  for (int q = 0; q < NE; ++q) eStep[q] = irregular ? G.xStep[wv][q] : G.eStep[q];
+  for (int q = 0; q < NE; ++q) eStep[q] = irregular ? G.xStep[xw][q] : G.eStep[q];
   const unsigned eLast5 = eStep[NE - 1] * (unsigned)(gLen - 1);
   // its edges, moved to the slots of the regular offsets they have (wave-uniform arithmetic)
   unsigned xe[NE], xk[NE], xact = 0;
   {
-    const int rowX = gStart * SELL_C + wv * 64 + (int)(X.lane & 63u), nx = (int)(X.info & 15u);
+    const int rowX = gStart * SELL_C + xw * 64 + (int)(X.lane & 63u), nx = (int)(X.info & 15u);
 #pragma unroll
     for (int q = 0; q < NE; ++q) {
       xe[q] = 0;
@@ -896,13 +906,22 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lag(SellView A, typ
 #pragma unroll
       for (int f = 0; f < (int)(sizeof(Edge) / sizeof(double)); ++f) pd[f] = dpp_from_lower_lane(ps[f], p0[f]);
     }
+    // (GY > 1: only the group's first / last line has a far neighbour outside the group)
+    const bool farM = GY == 1 || wv == 0, farP = GY == 1 || wv == GY - 1;
 #ifdef NG_LAG_NOY
     ym = own;
     yp = own;
 #else
-    if (act & 2u) ym = Op::load(P, row + D.ko[1]);
-    if (act & 16u) yp = Op::load(P, row + D.ko[4]);
+    if (farM && (act & 2u)) ym = Op::load(P, row + D.ko[1]);
+    if (farP && (act & 16u)) yp = Op::load(P, row + D.ko[4]);
 #endif
+    double *const ldsT = ldsY + (GY > 1 ? (t & 1) * GY * NF * 64 : 0);
+    if (GY > 1) {
+      const double *po = reinterpret_cast<const double *>(&own);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) ldsT[(wv * NF + f) * 64 + lane] = po[f];
+      __syncthreads();
+    }
     if (endLane) en = Op::load(P, row + endOff);
     double diag = 0.0, b = 0.0;
     double lhs[4], rh[2];
@@ -945,6 +964,11 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lag(SellView A, typ
         else A.vals[pos] += lhs[1];
       }
     };
+    if (GY > 1 && !farM) {
+      double *pn = reinterpret_cast<double *>(&ym);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) pn[f] = ldsT[((wv - 1) * NF + f) * 64 + lane];
+    }
     slot(1, ym);
     {
       Node xm;
@@ -961,6 +985,11 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lag(SellView A, typ
 #pragma unroll
       for (int f = 0; f < NF; ++f) pp[f] = dpp_from_upper_lane(po[f], pe[f]);
       slot(3, xp);
+    }
+    if (GY > 1 && !farP) {
+      double *pn = reinterpret_cast<double *>(&yp);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) pn[f] = ldsT[((wv + 1) * NF + f) * 64 + lane];
     }
     slot(4, yp);
     if (SET) {
@@ -1209,8 +1238,20 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
                h->dBurst && h->dMarch && !h->dEdgeOwned) {
       const int nPat = h->nMarchPat, nRest = h->nMarch - h->nMarchPat;
       if (nPat > 0 && lag_kernel(h)) {
-        if (set) k_assemble_rows_lag<Op, true><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
-        else k_assemble_rows_lag<Op, false><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+        // NG_ASM_LAG_GROUPS=1: groups of four runs of adjacent lines first (their rows meet in LDS: a quarter
+        // of the far gathers, one barrier per step), then the runs left over.  Measured, not the default:
+        // 256^3 1.014 against 0.973 ms, 512^3 7.19 against 7.51 ms (profiles/r3_lag_ablation.txt).
+        const bool grouped = getenv("NG_ASM_LAG_GROUPS") && atoi(getenv("NG_ASM_LAG_GROUPS")) != 0;
+        const int nG = grouped ? h->nMarchGroups : 0, nS = grouped ? h->nMarchSingles : nPat;
+        const int *singles = grouped ? h->dMarchSingles : nullptr;
+        if (nG > 0) {
+          if (set) k_assemble_rows_lag<Op, true, 4><<<4 * nG, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroups, 4 * nG);
+          else k_assemble_rows_lag<Op, false, 4><<<4 * nG, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroups, 4 * nG);
+        }
+        if (nS > 0) {
+          if (set) k_assemble_rows_lag<Op, true, 1><<<nS, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, singles, nS);
+          else k_assemble_rows_lag<Op, false, 1><<<nS, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, singles, nS);
+        }
       } else if (nPat > 0) {
         if (set) k_assemble_rows_march<Op, true><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
         else k_assemble_rows_march<Op, false><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);

@@ -179,7 +179,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dTags); NG_FREE(h->dDiagPos); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
-  NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dBurst); NG_FREE(h->dMarch); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
+  NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dBurst); NG_FREE(h->dMarch); NG_FREE(h->dMarchGroups); NG_FREE(h->dMarchSingles); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   for (auto &fd : h->flow) {
     NG_FREE(fd.dTicket); NG_FREE(fd.dChunks); NG_FREE(fd.dRowOf); NG_FREE(fd.dPubOf); NG_FREE(fd.dXch); NG_FREE(fd.dCode); NG_FREE(fd.dSteps); NG_FREE(fd.dSrc); NG_FREE(fd.dVal);
@@ -580,19 +580,22 @@ __device__ int march_pattern(const BurstSlice &a, int s, int nRows)
 }
 
 __global__ void k_march_links(int nSlices, int nRows, const BurstSlice *B, int *next, long long *offStep, int *pat,
-                              unsigned *eStep, int *lagOk)
+                              unsigned *eStep, int *lagOk, int *yOff)
 {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nSlices) return;
   next[s] = -1;
   offStep[s] = 0;
   lagOk[s] = 0;
+  yOff[2 * s] = yOff[2 * s + 1] = 0;
   for (int q = 0; q < 5 * BURST_NE; ++q) eStep[(size_t)s * 5 * BURST_NE + q] = 0u;
   const BurstSlice &a = B[s];
   pat[s] = march_pattern(a, s, nRows);
   if (!pat[s]) return;
   // the lagged kernel takes its in-slice neighbours from the lanes next door
   lagOk[s] = a.reg.ko[2] == -1 && a.reg.ko[3] == 1;
+  yOff[2 * s] = a.reg.ko[1];  // the far slots: on a lattice the lines below / above in the plane
+  yOff[2 * s + 1] = a.reg.ko[4];
   const int ne = BURST_NE;
   const int D = a.reg.ko[ne - 1];
   if (D <= 0 || D % SELL_C) return;
@@ -965,29 +968,32 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
     // runs of slices for the marching kernel: follow the links while step and storage stride stay
     // the same, at most MARCH_MAX_LEN slices per run; every slice is in exactly one run
     {
-      int *dNext = nullptr, *dPat = nullptr, *dLag = nullptr;
+      int *dNext = nullptr, *dPat = nullptr, *dLag = nullptr, *dYOff = nullptr;
       long long *dOffStep = nullptr;
       unsigned *dEStep = nullptr;
       NG_HIP(hipMalloc(&dNext, sizeof(int) * (size_t)h->nSlices));
       NG_HIP(hipMalloc(&dPat, sizeof(int) * (size_t)h->nSlices));
       NG_HIP(hipMalloc(&dLag, sizeof(int) * (size_t)h->nSlices));
+      NG_HIP(hipMalloc(&dYOff, sizeof(int) * 2 * (size_t)h->nSlices));
       NG_HIP(hipMalloc(&dOffStep, sizeof(long long) * (size_t)h->nSlices));
       NG_HIP(hipMalloc(&dEStep, sizeof(unsigned) * (size_t)h->nSlices * 5 * BURST_NE));
       k_march_links<<<(h->nSlices + 255) / 256, 256, 0, h->stream>>>(h->nSlices, nO, h->dBurst, dNext, dOffStep, dPat,
-                                                                      dEStep, dLag);
+                                                                      dEStep, dLag, dYOff);
       NG_HIP(hipGetLastError());
-      std::vector<int> nxt((size_t)h->nSlices), pat((size_t)h->nSlices), lagv((size_t)h->nSlices);
+      std::vector<int> nxt((size_t)h->nSlices), pat((size_t)h->nSlices), lagv((size_t)h->nSlices), yoff(2 * (size_t)h->nSlices);
       std::vector<long long> ost((size_t)h->nSlices);
       std::vector<unsigned> est((size_t)h->nSlices * 5 * BURST_NE);
       NG_HIP(hipStreamSynchronize(h->stream));
       NG_HIP(hipMemcpy(nxt.data(), dNext, sizeof(int) * nxt.size(), hipMemcpyDeviceToHost));
       NG_HIP(hipMemcpy(pat.data(), dPat, sizeof(int) * pat.size(), hipMemcpyDeviceToHost));
       NG_HIP(hipMemcpy(lagv.data(), dLag, sizeof(int) * lagv.size(), hipMemcpyDeviceToHost));
+      NG_HIP(hipMemcpy(yoff.data(), dYOff, sizeof(int) * yoff.size(), hipMemcpyDeviceToHost));
       NG_HIP(hipMemcpy(ost.data(), dOffStep, sizeof(long long) * ost.size(), hipMemcpyDeviceToHost));
       NG_HIP(hipMemcpy(est.data(), dEStep, sizeof(unsigned) * est.size(), hipMemcpyDeviceToHost));
       (void)hipFree(dNext);
       (void)hipFree(dPat);
       (void)hipFree(dLag);
+      (void)hipFree(dYOff);
       (void)hipFree(dOffStep);
       (void)hipFree(dEStep);
       const int maxLen = getenv("NG_MARCH_LEN") ? std::max(1, atoi(getenv("NG_MARCH_LEN"))) : MARCH_MAX_LEN;
@@ -1039,6 +1045,47 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
         h->marchSlices += g.len;
         h->marchLongest = std::max(h->marchLongest, g.len);
         h->marchLag = h->marchLag && g.lag;
+      }
+      // groups of four pattern runs of adjacent lines for k_assemble_rows_lag4: run r with the runs whose
+      // first slices lie one, two and three "far offsets" further on (ko[4] = -ko[1] = a whole number of
+      // slices: on a lattice the next line of the plane), same length and strides
+      {
+        std::vector<int> groups, singles;
+        if (h->marchLag) {
+          std::unordered_map<int, int> runAt;
+          for (int r = 0; r < h->nMarchPat; ++r) runAt[segs[(size_t)r].start] = r;
+          std::vector<char> used((size_t)h->nMarchPat, 0);
+          for (int r = 0; r < h->nMarchPat; ++r) {
+            if (used[(size_t)r]) continue;
+            const MarchSeg &g0 = segs[(size_t)r];
+            const int up = yoff[2 * (size_t)g0.start + 1], dn = yoff[2 * (size_t)g0.start];
+            int member[4] = {r, -1, -1, -1};
+            bool ok = up > 0 && up % SELL_C == 0 && dn == -up;
+            for (int q = 1; q < 4 && ok; ++q) {
+              auto it = runAt.find(g0.start + q * (up / SELL_C));
+              ok = it != runAt.end() && !used[(size_t)it->second];
+              if (!ok) break;
+              const MarchSeg &g = segs[(size_t)it->second];
+              ok = g.len == g0.len && g.step == g0.step && g.offStep == g0.offStep && g.rowStep == g0.rowStep &&
+                   yoff[2 * (size_t)g.start + 1] == up && yoff[2 * (size_t)g.start] == dn;
+              member[q] = it->second;
+            }
+            if (ok) {
+              for (int q = 0; q < 4; ++q) { used[(size_t)member[q]] = 1; groups.push_back(member[q]); }
+            } else {
+              used[(size_t)r] = 1;
+              singles.push_back(r);
+            }
+          }
+        }
+        h->nMarchGroups = (int)groups.size() / 4;
+        h->nMarchSingles = (int)singles.size();
+        NG_HIP(hipMalloc(&h->dMarchGroups, sizeof(int) * std::max<size_t>(groups.size(), 1)));
+        NG_HIP(hipMalloc(&h->dMarchSingles, sizeof(int) * std::max<size_t>(singles.size(), 1)));
+        if (!groups.empty())
+          NG_HIP(hipMemcpy(h->dMarchGroups, groups.data(), sizeof(int) * groups.size(), hipMemcpyHostToDevice));
+        if (!singles.empty())
+          NG_HIP(hipMemcpy(h->dMarchSingles, singles.data(), sizeof(int) * singles.size(), hipMemcpyHostToDevice));
       }
       segs.insert(segs.end(), others.begin(), others.end());
       h->nMarch = (int)segs.size();

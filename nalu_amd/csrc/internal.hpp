@@ -221,6 +221,9 @@ struct nalu_gpu_linsys {
   int marchLongest = 0;
   int marchXcdRun = 8;
   bool marchLag = false;  // every pattern run qualifies for the lagged, barrier-free marching kernel
+  // groups of four runs of adjacent lines (k_assemble_rows_lag4: the lines' rows next to each other in LDS)
+  int *dMarchGroups = nullptr, *dMarchSingles = nullptr;  // 4 run indices per group; the runs left over
+  int nMarchGroups = 0, nMarchSingles = 0;
   bool asmExplicit = false;              // an NG_ASM_* variable chose the assembly kernel   // nSlices (null: maxSliceWidth > BURST_W)
 
   // edges
