@@ -35,18 +35,23 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def pmc_traffic(dims):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*traffic.json,
-    collected on the 256^3 box by scripts/pmc_short.sh): counters cannot be collected inside this
-    run, so `traffic` is only reported for the workload they were measured on."""
-    for name in ("r2_traffic.json", "r1_traffic.json"):
-        try:
-            d = json.load(open(os.path.join(HERE, "profiles", name)))
-        except OSError:
-            continue
-        if tuple(dims) == (d.get("n"),) * 3:
-            d["source"] = "profiles/" + name
-            return d
-    return {}
+    """HBM bytes per launch of the hot kernels from the committed rocprofv3 --pmc passes
+    (profiles/r3_traffic.json, collected by scripts/r3_profile.sh on the 256^3 and 512^3 boxes):
+    counters cannot be collected inside this run, so `traffic` is only reported for the boxes they
+    were measured on.  Returns {kernel: record} and the source file."""
+    try:
+        d = json.load(open(os.path.join(HERE, "profiles", "r3_traffic.json")))
+    except OSError:
+        return {}, None
+    if dims[0] == dims[1] == dims[2] and str(dims[0]) in d.get("boxes", {}):
+        return d["boxes"][str(dims[0])], "profiles/r3_traffic.json"
+    return {}, None
+
+
+def traffic_of(pmc, names):
+    """sum of the HBM bytes per launch of the kernels that make up one launch (None if any is missing)"""
+    got = [pmc.get(n, {}).get("hbm_bytes") for n in names]
+    return None if (not got or any(v is None for v in got)) else float(sum(got))
 
 
 def box_counts(nx, ny, nz):
@@ -249,9 +254,12 @@ def main():
     ap.add_argument("--precond", default="jacobi", choices=["jacobi", "sgs", "mt_sgs", "chebyshev"],
                     help="preconditioner of the scalar workload's GMRES(50) (the reference's edge regression inputs use "
                          "sgs for transport, reg_tests/test_files/periodic3dEdge/periodic3dEdge.i:9-16)")
-    ap.add_argument("--workload", default="continuity", choices=["continuity", "scalar"],
+    ap.add_argument("--workload", default="continuity", choices=["continuity", "scalar", "picard"],
                     help="continuity = the headline Poisson step (default); scalar = BASELINE config 4: "
-                         "scalar transport edge assembly (upwind, limiter) + mass term + GMRES(50)/Jacobi")
+                         "scalar transport edge assembly (upwind, limiter) + mass term + GMRES(50)/Jacobi; "
+                         "picard = one iteration of the pressure-projection loop per step (continuity "
+                         "assemble_and_solve, p += dp, mdot, nodal gradient, velocity projection; "
+                         "src/LowMachEquationSystem.C:621-717), everything device resident")
     a = ap.parse_args()
 
     import torch
@@ -274,20 +282,23 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(device))
             # the library's own communicator (no Python per iteration); NALU_BENCH_COMM=torch, or a
             # failure to set it up on ANY rank, selects the torch.distributed callbacks instead
+            # Agreed in two steps so that no rank can sit alone inside ncclCommInitRank: first every rank
+            # loads libnalu_gpu_rccl.so (rank-local, cannot hang) and the MIN over ranks of "loaded" decides
+            # native vs torch; only then is the communicator created, by all ranks together.
             ok = 0
             if os.environ.get("NALU_BENCH_COMM", "native") == "native":
                 try:
-                    from nalu_amd.rccl import RcclWorld
-                    rworld = RcclWorld(rank, world, local)
+                    from nalu_amd import rccl
+                    rccl.load()
                     ok = 1
                 except Exception as e:  # noqa: BLE001 (reported, then the fallback runs)
-                    print(f"[bench] rank {rank}: native RCCL communicator unavailable ({e}); "
+                    print(f"[bench] rank {rank}: native RCCL library unavailable ({e}); "
                           f"falling back to torch.distributed", file=sys.stderr, flush=True)
             flag = torch.tensor([ok], dtype=torch.int32, device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0 and rworld is not None:
-                rworld.close()
-                rworld = None
+            if int(flag.item()) == 1:
+                # a failure in here is a failure of the RCCL job itself (it would fail torch's collectives too)
+                rworld = rccl.RcclWorld(rank, world, local)
         else:
             dist.init_process_group(backend)
 
@@ -304,6 +315,21 @@ def main():
                                           max_iterations=50, kspace=50)
         eq = R.scalar_eqsys(cfg, device, a.mode)
 
+    picard = None
+    if a.workload == "picard":
+        from nalu_amd import eqsys
+        F.update(vol=torch.as_tensor(R.vol, dtype=torch.float64, device=device),
+                 mdot=torch.zeros(S.n_edges, dtype=torch.float64, device=device))
+        eq.solverAlgDriver.solverAlgMap["REF_PRESSURE"] = eqsys.FixPressureAtNodeAlgorithm(0 if R.pin else None, 0.0, F["p"])
+        picard = eqsys.ContinuityProjectionLoop(eq, F, 0.1)
+
+        class _Step:  # timed_steps() calls assemble_and_solve(): one Picard iteration per step
+            def assemble_and_solve(self):
+                picard.solve_and_update(1)
+        eq_timed = _Step()
+    else:
+        eq_timed = eq
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -317,18 +343,29 @@ def main():
             dt = float(tt.item())
         return dt
 
-    dt = max_over_ranks(timed_steps(eq, g, a.steps, a.warmup, barrier))
+    dt = max_over_ranks(timed_steps(eq_timed, g, a.steps, a.warmup, barrier))
     asm_ms, asm_cnt = g.timer("assemble_edges")
     spmv_ms, spmv_cnt = g.timer("spmv")
     spmv_launches = g.timer_launches("spmv")
     solve_ms, _ = g.timer("solve")
     iters = g.linearSolveIterations
     g.set_profiling(False)
+    picard_rec = None
+    if picard is not None:  # where a Picard iteration spends its time (host clocks around synchronised phases)
+        for k in picard.timer:
+            picard.timer[k] = 0.0
+        for _ in range(3):
+            picard.solve_and_update(1, sync=g.synchronize)
+        picard_rec = {k + "_ms": v / 3 * 1e3 for k, v in picard.timer.items()}
+        picard_rec["note"] = ("phases of one iteration, each bracketed by a stream synchronisation (3 iterations after the "
+                              "timed region): assemble_and_solve = zero + continuity edges + pin + 50 Jacobi-CG iterations, "
+                              "update = p += dp, mdot = ComputeMdotEdge, project = save dpdx + nodal gradient + u -= tau/rho dG")
     layout = g.layout_info()
 
     # algorithmic bytes: per-rank local sizes
     Nl, El, nnzl = S.n_owned, S.n_edges, g.nnz
-    asm_bytes = (40 * El + 104 * Nl if a.workload == "scalar" else 32 * El + 96 * Nl) + 8 * nnzl
+    scalar = a.workload == "scalar"
+    asm_bytes = (40 * El + 104 * Nl if scalar else 32 * El + 96 * Nl) + 8 * nnzl
     spmv_bytes = 12 * nnzl + 4 * (Nl + 1) + 16 * Nl
     asm_t = asm_ms / max(asm_cnt, 1) * 1e-3
     spmv_t = spmv_ms / max(spmv_cnt, 1) * 1e-3
@@ -416,12 +453,13 @@ def main():
 
     out = None
     if rank == 0:
-        pmc = pmc_traffic(dims)
+        pmc, pmc_src = pmc_traffic(dims)
         nx, ny, nz = dims
-        step_txt = ("continuity edge assembly + pinned node + Jacobi-CG (tol 1e-5, max_it 50)"
-                    if a.workload == "continuity" else
-                    "scalar transport edge assembly (upwind, van Leer limiter) + mass term + "
-                    f"GMRES(50)/{a.precond} (tol 1e-5, max_it 50)")
+        step_txt = {"continuity": "continuity edge assembly + pinned node + Jacobi-CG (tol 1e-5, max_it 50)",
+                    "scalar": "scalar transport edge assembly (upwind, van Leer limiter) + mass term + "
+                              f"GMRES(50)/{a.precond} (tol 1e-5, max_it 50)",
+                    "picard": "one Picard iteration of the pressure projection: continuity edge assembly + pinned node + "
+                              "Jacobi-CG (tol 1e-5, max_it 50), p += dp, mdot, nodal gradient, velocity projection"}[a.workload]
         if world == 1:
             wl = f"Hex8 box {n}^3 nodes on one GPU: "
         elif a.scaling == "strong":
@@ -429,11 +467,18 @@ def main():
         else:
             wl = (f"Hex8 box {nx}x{ny}x{nz} nodes, {n}^3 = {Nl} nodes per GPU as z-slabs of {nz // world} "
                   f"element layers (N = 8: the 512^3 box of config 5): ")
-        op = "ContOp" if a.workload == "continuity" else "ScalOp"
+        op = "ScalOp" if scalar else "ContOp"
         asm_kernel = f"k_assemble_rows<{op}> ({a.mode})"
-        if a.mode == "rows" and a.workload == "continuity" and layout["assembly_variant"] == 4:
-            asm_kernel = (f"k_assemble_rows_march<{op}> over {layout['march_runs']} runs of slices "
+        asm_parts = [f"k_assemble_rows<{op}>"]
+        if a.mode == "rows" and layout["assembly_variant"] in (4, 5) and (layout["assembly_variant"] == 5 or not scalar):
+            main = "k_assemble_rows_lag" if layout["assembly_variant"] == 5 else "k_assemble_rows_march"
+            asm_kernel = (f"{main}<{op}> over {layout['march_runs']} runs of slices "
                           f"({layout['march_slices']} of {layout['n_slices']} slices) + k_assemble_rows_burst for the rest")
+            asm_parts = [f"{main}<{op}>", f"k_assemble_rows_burst<{op}>"]
+        spmv_name = "k_spmv<DINV>" if scalar else "k_spmv<DOT>"
+        spmv_traffic = traffic_of(pmc, [spmv_name])
+        asm_traffic = traffic_of(pmc, asm_parts) if a.mode == "rows" else None
+        frac_of = lambda nbytes, t: None if nbytes is None else nbytes / t / 1e9 / HBM_PEAK_GBS
         env_knobs = {k: v for k, v in os.environ.items() if k.startswith("NG_") or k in ("NALU_EDGE_ORDER",)}
         out = {
             "metric": "edges assembled/s + SpMV GB/s (% HBM peak), Hex8 256^3 Poisson, 1-8 GPUs",
@@ -450,25 +495,31 @@ def main():
                        "rows_computed_tags": layout["rows_computed_tags"],
                        "rows_computed_columns": layout["rows_computed_columns"],
                        "env_knobs": env_knobs},
-            "roofline": {"kernel": "k_spmv<DOT> (SELL-256 SpMV fused with p.Ap)" if a.workload == "continuity"
-                         else "k_spmv<DINV> (SELL-256 SpMV with the right-preconditioner column scaling)",
+            # the assembly-only rate over all GPUs (the headline's first half; `value` is edges through the WHOLE step)
+            "assembly_edges_per_s": El * world / asm_t,
+            "roofline": {"kernel": "k_spmv<DINV> (SELL-256 SpMV with the right-preconditioner column scaling)" if scalar
+                         else "k_spmv<DOT> (SELL-256 SpMV fused with p.Ap)",
                          "bound": "hbm",
                          "achieved": spmv_bytes / spmv_t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": spmv_bytes / spmv_t / 1e9 / HBM_PEAK_GBS,
-                         "traffic": pmc.get("k_spmv", {}).get("hbm_bytes") if a.workload == "continuity" else None,
+                         # counter bytes / time / peak: what the hardware moved (the kernel computes most column indices
+                         # instead of loading them, so it moves fewer bytes than SURVEY's plain-CSR count charges it)
+                         "traffic": spmv_traffic, "frac_traffic": frac_of(spmv_traffic, spmv_t),
                          "algorithmic_bytes": spmv_bytes, "avg_ms": spmv_t * 1e3,
                          "launches": spmv_launches, "timed_launches": spmv_cnt},
             "roofline_assembly": {"kernel": asm_kernel, "bound": "hbm",
                                   "achieved": asm_bytes / asm_t / 1e9, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": asm_bytes / asm_t / 1e9 / HBM_PEAK_GBS,
-                                  "traffic": pmc.get("k_assemble_rows", {}).get("hbm_bytes") if a.workload == "continuity" else None,
+                                  "traffic": asm_traffic, "frac_traffic": frac_of(asm_traffic, asm_t),
                                   "algorithmic_bytes": asm_bytes,
                                   "avg_ms": asm_t * 1e3, "launches": asm_cnt,
                                   "edges_per_s_per_gpu": El / asm_t},
             "solve_ms_per_iteration": solve_ms / a.steps / max(iters, 1),
         }
-        if pmc:
-            out["roofline"]["traffic_source"] = out["roofline_assembly"]["traffic_source"] = pmc.get("source")
+        if pmc_src:
+            out["roofline"]["traffic_source"] = out["roofline_assembly"]["traffic_source"] = pmc_src
+        if picard_rec:
+            out["picard"] = picard_rec
         if variants:
             out["scatter_variants"] = variants
         if ttt:
@@ -476,7 +527,8 @@ def main():
         if strong:
             out["strong"] = strong
         if world == 1 and a.cpu_n > 0:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.workload, a.precond)
+            # (picard: the continuity step, which is what `value` counts edges through)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_n, "scalar" if scalar else "continuity", a.precond)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
