@@ -35,6 +35,20 @@ struct ContOp {
     a.rho = P.f.density[n];
     return a;
   }
+  // the f-th nodal / c-th edge field in the order of Node / Edge (the prefetching kernel addresses them by index)
+  __device__ static __forceinline__ const double *node_field(const Params &P, int f)
+  {
+    const double *const F[11] = {P.f.coordinates.x, P.f.coordinates.y, P.f.coordinates.z, P.f.dpdx.x, P.f.dpdx.y, P.f.dpdx.z,
+                                 P.f.velocity.x, P.f.velocity.y, P.f.velocity.z, P.f.pressure, P.f.density};
+    const double *r = F[0];
+#pragma unroll
+    for (int i = 1; i < 11; ++i) r = f == i ? F[i] : r;
+    return r;
+  }
+  __device__ static __forceinline__ const double *edge_field(const Params &P, int c)
+  {
+    return c == 0 ? P.f.edge_area.x : c == 1 ? P.f.edge_area.y : P.f.edge_area.z;
+  }
   struct Edge {
     double av[3];
   };
@@ -123,6 +137,20 @@ struct ScalOp {
   __device__ static __forceinline__ double van_leer(double dqm, double dqp, double small)
   {
     return (2.0 * (dqm * dqp + fabs(dqm * dqp))) / ((dqm + dqp) * (dqm + dqp) + small);
+  }
+  __device__ static __forceinline__ const double *node_field(const Params &P, int f)
+  {
+    const double *const F[12] = {P.f.coordinates.x, P.f.coordinates.y, P.f.coordinates.z, P.f.dqdx.x, P.f.dqdx.y, P.f.dqdx.z,
+                                 P.f.velocity.x, P.f.velocity.y, P.f.velocity.z, P.f.scalar_q, P.f.density,
+                                 P.f.diff_flux_coeff};
+    const double *r = F[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) r = f == i ? F[i] : r;
+    return r;
+  }
+  __device__ static __forceinline__ const double *edge_field(const Params &P, int c)
+  {
+    return c == 0 ? P.f.edge_area.x : c == 1 ? P.f.edge_area.y : c == 2 ? P.f.edge_area.z : P.f.mass_flow_rate;
   }
   struct Edge {
     double av[3], mdot;
@@ -1028,6 +1056,318 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lag(SellView A, typ
   else rhs[row] += pRhs;
 }
 
+// The lagged kernel with its streamed operands PREFETCHED INTO LDS (round 3, NG_ASM_LAG_PF): what a step reads
+// from HBM -- the wave's own 64 rows of every nodal field and the edge data of slots 0, 1, 3, 4 -- is requested one
+// step ahead by direct-to-LDS loads (global_load_lds_dwordx4: lane l's 16 bytes land at base + 16 l, no register
+// is held, scripts/ldsdma_probe.hip), lanes 0-31 fetching one field and lanes 32-63 the next.  A step
+// (A) waits for its prefetch (the wave's one in-order memory counter: everything issued before is done) and
+// copies it to registers, (E) issues the prefetch of the NEXT step at once, evaluates its edges while that is in
+// flight, and (B) at its end issues the few loads of the next step that are L2 hits (far rows, the end lanes' x
+// neighbours) into registers it no longer needs.  Same fluxes in the same order as k_assemble_rows_lag:
+// bit-identical.
+// GY = 1: a workgroup = the four quarters of one run; each wave owns its LDS region: no barrier, no flags; the
+// y neighbours' rows are loads (B).
+// GY = 4: a workgroup = the same quarter of FOUR runs of adjacent lines (the groups of NG_ASM_LAG_GROUPS); the
+// nodal part of a wave's region is double-buffered and the waves read their y neighbours' rows out of the
+// NEIGHBOURING WAVE'S region (one barrier per step, right behind the wait (A): every wave's prefetch has landed
+// and nobody reads the buffer the next prefetch overwrites).  A row is then fetched from HBM once per group
+// and by the two groups next door, and the y neighbours hold no registers.
+// Edge ids of the prefetch follow the regular rows' pattern (id = tb + row); a wave's irregular row whose ids
+// do not, and a wave at the very end of the edge array (a 16-byte load would leave it), load those edges
+// themselves.
+template <class Op, int GY> struct PfLayout {
+  static constexpr int NF = sizeof(typename Op::Node) / sizeof(double), NEF = sizeof(typename Op::Edge) / sizeof(double);
+  static constexpr int NFP = (NF + 1) / 2 * 2;      // nodal fields, padded to pairs (one load = two fields)
+  static constexpr int NS = 4;                      // prefetched edge slots: 0, 1, 3, 4
+  static constexpr int NB = GY > 1 ? 2 : 1;         // nodal buffers
+  static constexpr int kDoubles = (NB * NFP + NS * NEF) * 64;  // per wave
+  __host__ __device__ static constexpr int slot(int k) { return k < 2 ? k : k + 1; }
+};
+
+template <class Op, bool SET, int GY>
+__global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lagpf(SellView A, typename Op::Params P,
+                                                                  double *__restrict__ rhs,
+                                                                  const int *__restrict__ list, int nItems,
+                                                                  long long nEdges)
+{
+  using Node = typename Op::Node;
+  using Edge = typename Op::Edge;
+  using L = PfLayout<Op, GY>;
+  constexpr int NF = L::NF, NEF = L::NEF, NFP = L::NFP, NS = L::NS;
+  constexpr int NE = BURST_NE;
+  static_assert((NS * NEF) % 2 == 0, "edge fields are fetched in pairs");
+  static_assert(GY == 1 || GY == SELL_C / 64, "a group is one line per wave");
+  __shared__ double ldsAll[SELL_C / 64 * L::kDoubles];
+  const int r = threadIdx.x, lane = r & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(r >> 6);
+  const int item = xcd_run(blockIdx.x, nItems, GY > 1 ? A.marchXcdRun * GY : A.marchXcdRun);
+  const int xw = GY > 1 ? (item & (GY - 1)) : wv;  // which 64-row quarter of its slices the wave walks
+  // (GY > 1: a group may have fewer than GY lines: run index -1; such a wave only keeps the barriers company)
+  const int ridx = GY > 1 ? list[(item & ~(GY - 1)) + wv] : (list ? list[item] : item);
+  if (GY > 1 && ridx < 0) {
+    const int n = A.march[list[item & ~(GY - 1)]].len;
+    for (int t = 0; t < n; ++t) __syncthreads();
+    return;
+  }
+  const MarchSeg &G = A.march[ridx];
+  const int gStart = G.start, gLen = G.len, gRowStep = G.rowStep;
+  const long long gOffStep = G.offStep;
+  const int rowW = gStart * SELL_C + xw * 64;  // the wave's first row
+  int row = rowW + lane;
+  const BurstSlice *const S = A.burst + gStart;
+  const BurstRow D = S->reg, X = S->irr[xw];
+  const int w = S->w;
+  const unsigned long long mI = S->irrMask[xw];
+  long long pos0 = S->off + xw * 64 + lane;
+  const bool irregular = (mI >> lane) & 1ULL;
+  unsigned eStep[NE];
+#pragma unroll
+  for (int q = 0; q < NE; ++q) eStep[q] = irregular ? G.xStep[xw][q] : G.eStep[q];
+  const unsigned eLast5 = eStep[NE - 1] * (unsigned)(gLen - 1);
+  unsigned xe[NE], xk[NE], xact = 0, xown = 0;  // xown: slots in which the irregular row's ids leave the pattern
+  {
+    const int rowX = rowW + (int)(X.lane & 63u), nx = (int)(X.info & 15u);
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      xe[q] = 0;
+      xk[q] = 0;
+#pragma unroll
+      for (int e = 0; e < NE; ++e)
+        if (e < nx && X.ko[e] - rowX == D.ko[q]) {
+          xe[q] = X.tb[e];
+          xk[q] = (X.kl >> (4 * e)) & 15u;
+          xact |= 1u << q;
+          if (X.tb[e] != D.tb[q] + (unsigned)rowX || G.xStep[xw][q] != G.eStep[q]) xown |= 1u << q;
+        }
+    }
+  }
+  unsigned eid[NE], kkAll = 0;
+#pragma unroll
+  for (int q = 0; q < NE; ++q) {
+    eid[q] = irregular ? xe[q] : D.tb[q] + (unsigned)row;
+    kkAll |= (irregular ? xk[q] : (D.kl >> (4 * q)) & 15u) << (4 * q);
+  }
+  auto kk = [&](int q) { return (long long)((kkAll >> (4 * q)) & 15u); };
+  const unsigned act = irregular ? xact : (1u << NE) - 1u;
+  const unsigned own_ids = irregular ? xown : 0u;
+  const bool ownAny = __builtin_amdgcn_readfirstlane((int)(__ballot(own_ids != 0u) != 0ULL)) != 0;
+  const unsigned info = irregular ? X.info : D.info;
+  const int kDiag = (int)((info >> 4) & 15u) - 1;
+  const unsigned zeroMask = (info >> 8) & 255u;
+  const bool endLane = (lane == 0 && (act & 4u)) || (lane == 63 && (act & 8u));
+  const int endOff = lane == 0 ? -1 : 1;
+  // (GY > 1: only the group's first / last line has a far neighbour outside the group)
+  const bool farM = GY == 1 || wv == 0,
+             farP = GY == 1 || wv == GY - 1 || list[(item & ~(GY - 1)) + min(wv + 1, GY - 1)] < 0;
+  // ---- the prefetch: ids of the wave's first row in the prefetched slots (wave-uniform, one step ahead)
+  double *const ldsW = ldsAll + wv * L::kDoubles;
+  double *const ldsE = ldsW + L::NB * NFP * 64;
+  const int half = lane >> 5, l2 = 2 * (lane & 31);
+  unsigned pfId[NS], pfStep[NS];  // (scalar registers: a vector load here would make the loop wait for its own prefetch)
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    pfId[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)(D.tb[L::slot(k)] + (unsigned)rowW));
+    pfStep[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)G.eStep[L::slot(k)]);
+  }
+  auto prefetch = [&](int rowN, int buf) {  // rowN: the wave's first row of the step to fetch; pfId: that step's ids
+    double *const dstN = ldsW + buf * NFP * 64;
+#pragma unroll
+    for (int i = 0; i < NFP / 2; ++i) {
+      const double *src = (half ? Op::node_field(P, min(2 * i + 1, NF - 1)) : Op::node_field(P, 2 * i)) + rowN + l2;
+      if (2 * i + 1 < NF || !half)
+        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(dstN + i * 128), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NS * NEF / 2; ++i) {
+      const int g0 = 2 * i, g1 = 2 * i + 1;
+      const long long id = (long long)((half ? pfId[g1 / NEF] : pfId[g0 / NEF]) & 0x7FFFFFFFu) + l2;
+      const double *src = (half ? Op::edge_field(P, g1 % NEF) : Op::edge_field(P, g0 % NEF)) + id;
+      if (id + 1 < nEdges)
+        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(ldsE + i * 128), 16, 0, 0);
+    }
+  };
+  prefetch(rowW, 0);
+  Node prev;
+  double pDiag = 0.0, pRhs = 0.0;
+  if (act & 1u) prev = Op::load(P, row + D.ko[0]);
+  // (B) the loads that hit the L2 -- far rows, the end lanes' x neighbours, the first lane's edge to the lane
+  // below -- are issued at the END of the previous step, into registers that step no longer needs
+  Node ym, yp, en;  // (GY > 1: ym doubles as the one far row a wave at the end of its group has)
+  Edge e0, E2;      // (kDppArea: e0 = the first lane's edge to the lane below, the others shift in the lower lane's slot 3)
+  auto loadB = [&]() {
+    if (LagCfg<Op>::kDppArea) {
+      if (lane == 0 && (act & 4u)) e0 = Op::load_edge(P, (long long)(eid[2] & 0x7FFFFFFFu));
+    } else if (act & 4u) {
+      E2 = Op::load_edge(P, (long long)(eid[2] & 0x7FFFFFFFu));
+    }
+    if (GY == 1) {
+      if (act & 2u) ym = Op::load(P, row + D.ko[1]);
+      if (act & 16u) yp = Op::load(P, row + D.ko[4]);
+    } else if (farM) {
+      if (act & 2u) ym = Op::load(P, row + D.ko[1]);
+    } else if (farP) {
+      if (act & 16u) ym = Op::load(P, row + D.ko[4]);
+    }
+    if (endLane) en = Op::load(P, row + endOff);
+  };
+  loadB();
+  for (int t = 0; t < gLen; ++t) {
+    // ---- (A) this step's prefetch and (B) have landed (and the last step's stores are acknowledged): LDS -> registers
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    asm volatile("" ::: "memory");
+    if (GY > 1) __syncthreads();
+    const int cur = GY > 1 ? (t & 1) : 0;
+    const double *const ldsN = ldsW + cur * NFP * 64;
+    Node own;
+    Edge E[NE - 1];
+    {
+      double *po = reinterpret_cast<double *>(&own);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) po[f] = ldsN[f * 64 + lane];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        double *pe = reinterpret_cast<double *>(&E[L::slot(k)]);
+#pragma unroll
+        for (int c = 0; c < NEF; ++c) pe[c] = ldsE[(k * NEF + c) * 64 + lane];
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own region may be overwritten from here on
+    {
+      // the rare wave whose prefetch did not bring every lane's edges: ids off the pattern (ownAny), or the
+      // 16-byte loads would have left the edge array.  A wave-uniform branch that ends with a full wait.
+      bool slow = ownAny;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) slow = slow || (long long)(pfId[k] & 0x7FFFFFFFu) + 64 > nEdges;
+      if (slow) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          const int e = L::slot(k);
+          const bool mine = ((own_ids >> e) & 1u) || (long long)(pfId[k] & 0x7FFFFFFFu) + 64 > nEdges;
+          if (((act >> e) & 1u) && mine) E[e] = Op::load_edge(P, (long long)(eid[e] & 0x7FFFFFFFu));
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+      }
+    }
+    // ---- (E) the next step's prefetch, as early as the region is free
+    if (t + 1 < gLen) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) pfId[k] += pfStep[k];
+      prefetch(rowW + (t + 1) * gRowStep, GY > 1 ? (cur ^ 1) : 0);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    double diag = 0.0, b = 0.0;
+    double lhs[4], rh[2];
+    if (act & 1u) LAG_EDGE(P, Op::mirrored(E[0], (eid[0] >> 31) != 0), own, prev, lhs, rh);
+    if (LagCfg<Op>::kDppArea) {
+      const double *ps = reinterpret_cast<const double *>(&E[3]), *p0 = reinterpret_cast<const double *>(&e0);
+      double *pd = reinterpret_cast<double *>(&E[2]);
+#pragma unroll
+      for (int f = 0; f < NEF; ++f) pd[f] = dpp_from_lower_lane(ps[f], p0[f]);
+    } else {
+      E[2] = E2;
+    }
+    if (act & 1u) {
+      diag += lhs[0];
+      b += rh[0];
+      const long long pos = pos0 + kk(0) * SELL_C;
+      if (SET) LAG_ST(A.vals + pos, lhs[1]);
+      else A.vals[pos] += lhs[1];
+    }
+    if (t > 0) {
+      const long long posP = pos0 - gOffStep;
+      if (act & 32u) {
+        pDiag += lhs[3];
+        pRhs += rh[1];
+        const long long pos = posP + kk(NE - 1) * SELL_C;
+        if (SET) LAG_ST(A.vals + pos, lhs[2]);
+        else A.vals[pos] += lhs[2];
+      }
+      if (kDiag >= 0) {
+        const long long pos = posP + (long long)kDiag * SELL_C;
+        if (SET) LAG_ST(A.vals + pos, pDiag);
+        else A.vals[pos] += pDiag;
+      }
+      if (SET) LAG_ST(rhs + row - gRowStep, pRhs);
+      else rhs[row - gRowStep] += pRhs;
+    }
+    auto slot = [&](int e, const Node &nb) {
+      if ((act >> e) & 1u) {
+        LAG_EDGE(P, Op::mirrored(E[e], (eid[e] >> 31) != 0), own, nb, lhs, rh);
+        diag += lhs[0];
+        b += rh[0];
+        const long long pos = pos0 + kk(e) * SELL_C;
+        if (SET) LAG_ST(A.vals + pos, lhs[1]);
+        else A.vals[pos] += lhs[1];
+      }
+    };
+    // a y neighbour inside the group: the neighbouring wave's row of this step, out of its LDS region
+    auto group_row = [&](int v) {
+      Node nb;
+      double *pn = reinterpret_cast<double *>(&nb);
+      const double *src = ldsAll + v * L::kDoubles + cur * NFP * 64;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) pn[f] = src[f * 64 + lane];
+      return nb;
+    };
+    if (GY == 1 || farM) slot(1, ym);
+    else slot(1, group_row(wv - 1));
+    {
+      Node xm;
+      const double *po = reinterpret_cast<const double *>(&own), *pe = reinterpret_cast<const double *>(&en);
+      double *pm = reinterpret_cast<double *>(&xm);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) pm[f] = dpp_from_lower_lane(po[f], pe[f]);
+      slot(2, xm);
+    }
+    {
+      Node xp;
+      const double *po = reinterpret_cast<const double *>(&own), *pe = reinterpret_cast<const double *>(&en);
+      double *pp = reinterpret_cast<double *>(&xp);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) pp[f] = dpp_from_upper_lane(po[f], pe[f]);
+      slot(3, xp);
+    }
+    if (GY == 1) slot(4, yp);
+    else if (farP) slot(4, ym);
+    else slot(4, group_row(wv + 1));
+    if (SET) {
+      for (int k = 0; k < w; ++k)
+        if ((zeroMask >> k) & 1u) A.vals[pos0 + (long long)k * SELL_C] = 0.0;
+    }
+    // ---- step
+    prev = own;
+    pDiag = diag;
+    pRhs = b;
+    if (t + 1 < gLen) {
+#pragma unroll
+      for (int q = 0; q < NE - 1; ++q) eid[q] += eStep[q];
+      row += gRowStep;
+      pos0 += gOffStep;
+      loadB();
+    }
+  }
+  if (act & 32u) {
+    double lhs[4], rh[2];
+    eid[NE - 1] += eLast5;
+    LAG_EDGE(P, Op::mirrored(Op::load_edge(P, (long long)(eid[NE - 1] & 0x7FFFFFFFu)), (eid[NE - 1] >> 31) != 0), prev,
+             Op::load(P, row + D.ko[NE - 1]), lhs, rh);
+    pDiag += lhs[0];
+    pRhs += rh[0];
+    const long long pos = pos0 + kk(NE - 1) * SELL_C;
+    if (SET) LAG_ST(A.vals + pos, lhs[1]);
+    else A.vals[pos] += lhs[1];
+  }
+  if (kDiag >= 0) {
+    const long long pos = pos0 + (long long)kDiag * SELL_C;
+    if (SET) LAG_ST(A.vals + pos, pDiag);
+    else A.vals[pos] += pDiag;
+  }
+  if (SET) LAG_ST(rhs + row, pRhs);
+  else rhs[row] += pRhs;
+}
+
 // Entry-parallel row gather, persistent: a workgroup of NW waves assembles one QUARTER slice
 // (64 rows) per iteration; wave k evaluates the k-th entry of those 64 rows (for w > NW:
 // entries k, k + NW, ...), so the loads of a row's edges -- edge data and out-of-quarter
@@ -1242,13 +1582,23 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
         // of the far gathers, one barrier per step), then the runs left over.  Measured, not the default:
         // 256^3 1.014 against 0.973 ms, 512^3 7.19 against 7.51 ms (profiles/r3_lag_ablation.txt).
         const bool grouped = getenv("NG_ASM_LAG_GROUPS") && atoi(getenv("NG_ASM_LAG_GROUPS")) != 0;
+        // NG_ASM_LAG_PF=1: the variants that prefetch a step's streamed operands into LDS (k_assemble_rows_lagpf)
+        const bool pf = getenv("NG_ASM_LAG_PF") && atoi(getenv("NG_ASM_LAG_PF")) != 0 && h->nEdges >= 64;
         const int nG = grouped ? h->nMarchGroups : 0, nS = grouped ? h->nMarchSingles : nPat;
         const int *singles = grouped ? h->dMarchSingles : nullptr;
-        if (nG > 0) {
+        if (grouped && pf) {  // (every pattern run in one launch: incomplete groups have idle waves)
+          const int nP = h->nMarchGroupsP;
+          if (set) k_assemble_rows_lagpf<Op, true, 4><<<4 * nP, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, 4 * nP, h->nEdges);
+          else k_assemble_rows_lagpf<Op, false, 4><<<4 * nP, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, 4 * nP, h->nEdges);
+        } else if (nG > 0) {
           if (set) k_assemble_rows_lag<Op, true, 4><<<4 * nG, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroups, 4 * nG);
           else k_assemble_rows_lag<Op, false, 4><<<4 * nG, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroups, 4 * nG);
         }
-        if (nS > 0) {
+        if (grouped && pf) {
+        } else if (nS > 0 && pf) {
+          if (set) k_assemble_rows_lagpf<Op, true, 1><<<nS, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, singles, nS, h->nEdges);
+          else k_assemble_rows_lagpf<Op, false, 1><<<nS, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, singles, nS, h->nEdges);
+        } else if (nS > 0) {
           if (set) k_assemble_rows_lag<Op, true, 1><<<nS, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, singles, nS);
           else k_assemble_rows_lag<Op, false, 1><<<nS, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, singles, nS);
         }

@@ -224,6 +224,8 @@ struct nalu_gpu_linsys {
   // groups of four runs of adjacent lines (k_assemble_rows_lag4: the lines' rows next to each other in LDS)
   int *dMarchGroups = nullptr, *dMarchSingles = nullptr;  // 4 run indices per group; the runs left over
   int nMarchGroups = 0, nMarchSingles = 0;
+  int *dMarchGroupsP = nullptr;  // every pattern run in groups of up to four adjacent lines, -1 = no member (lagpf kernel)
+  int nMarchGroupsP = 0;
   bool asmExplicit = false;              // an NG_ASM_* variable chose the assembly kernel   // nSlices (null: maxSliceWidth > BURST_W)
 
   // edges

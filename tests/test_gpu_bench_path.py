@@ -141,7 +141,7 @@ SLOT_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", ["default", "row", "NG_ASM_BURST", "NG_ASM_MARCH", "lag_off", "lag_groups"])
+@pytest.mark.parametrize("variant", ["default", "row", "NG_ASM_BURST", "NG_ASM_MARCH", "lag_off", "lag_groups", "lag_pf", "lag_pf_groups"])
 @pytest.mark.parametrize("dims,perturb,min_computed", SLOT_CASES)
 def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, perturb, min_computed, variant):
     """default: the automatic choice (the marching kernel where at least half of the slices are in
@@ -154,6 +154,11 @@ def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, pert
     elif variant == "lag_off":  # round 2's marching kernel (LDS + one barrier per step) instead of the lagged one
         monkeypatch.setenv("NG_ASM_LAG", "0")
     elif variant == "lag_groups":  # four runs of adjacent lines per workgroup, their rows shared through LDS
+        monkeypatch.setenv("NG_ASM_LAG_GROUPS", "1")
+    elif variant == "lag_pf":  # a step's streamed operands prefetched into LDS one step ahead (direct-to-LDS loads)
+        monkeypatch.setenv("NG_ASM_LAG_PF", "1")
+    elif variant == "lag_pf_groups":  # ... and four adjacent lines per workgroup that read each other's rows from LDS
+        monkeypatch.setenv("NG_ASM_LAG_PF", "1")
         monkeypatch.setenv("NG_ASM_LAG_GROUPS", "1")
     elif variant != "default":
         monkeypatch.setenv(variant, "1")
@@ -168,7 +173,8 @@ def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, pert
     lag = 5 if li["march_runs"] > 0 else 4
     assert li["assembly_variant"] == {"default": lag if marching else 0, "row": 0, "NG_ASM_BURST": 3,
                                       "NG_ASM_MARCH": lag, "lag_off": 4 if marching else 0,
-                                      "lag_groups": lag if marching else 0}[variant], li
+                                      "lag_groups": lag if marching else 0, "lag_pf": lag if marching else 0,
+                                      "lag_pf_groups": lag if marching else 0}[variant], li
     if dims == (256, 6, 20):  # 4 interior lines x 18 interior planes: runs of 16 + 2 slices
         assert marching and li["march_longest"] == 16 and li["march_slices"] == 72 and li["march_runs"] == 8, li
     if dims == (512, 6, 20):  # ... two slices per line
