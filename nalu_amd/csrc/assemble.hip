@@ -825,6 +825,11 @@ __device__ __forceinline__ void lag_fake_edge(const typename Op::Params &, const
 #else
 #define LAG_EDGE(...) Op::edge(__VA_ARGS__)
 #endif
+#ifdef NG_LAG_NOFAR
+#define LAG_FAR(r) prev
+#else
+#define LAG_FAR(r) Op::load(P, (r))
+#endif
 #if defined(NG_LAG_NOSTORE)
 #define LAG_ST(p, v) do { if ((v) == 1.2345e300) *(p) = (v); } while (0)
 #else
@@ -1085,7 +1090,7 @@ template <class Op, int GY> struct PfLayout {
 };
 
 template <class Op, bool SET, int GY>
-__global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lagpf(SellView A, typename Op::Params P,
+__global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_assemble_rows_lagpf(SellView A, typename Op::Params P,
                                                                   double *__restrict__ rhs,
                                                                   const int *__restrict__ list, int nItems,
                                                                   long long nEdges)
@@ -1096,16 +1101,19 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lagpf(SellView A, t
   constexpr int NF = L::NF, NEF = L::NEF, NFP = L::NFP, NS = L::NS;
   constexpr int NE = BURST_NE;
   static_assert((NS * NEF) % 2 == 0, "edge fields are fetched in pairs");
-  static_assert(GY == 1 || GY == SELL_C / 64, "a group is one line per wave");
-  __shared__ double ldsAll[SELL_C / 64 * L::kDoubles];
+  static_assert(GY == 1 || GY == 4 || GY == 8, "a group is one line per wave");
+  constexpr int NW = GY > 1 ? GY : SELL_C / 64;  // waves per workgroup
+  constexpr int QS = SELL_C / 64;                // quarters per slice: a group is QS consecutive items
+  __shared__ double ldsAll[NW * L::kDoubles];
   const int r = threadIdx.x, lane = r & 63;
   const int wv = __builtin_amdgcn_readfirstlane(r >> 6);
-  const int item = xcd_run(blockIdx.x, nItems, GY > 1 ? A.marchXcdRun * GY : A.marchXcdRun);
-  const int xw = GY > 1 ? (item & (GY - 1)) : wv;  // which 64-row quarter of its slices the wave walks
+  const int item = xcd_run(blockIdx.x, nItems, GY > 1 ? A.marchXcdRun * (SELL_C / 64) : A.marchXcdRun);
+  const int xw = GY > 1 ? (item & (QS - 1)) : wv;  // which 64-row quarter of its slices the wave walks
+  const int gBase = GY > 1 ? (item / QS) * GY : 0;  // the group's first entry in the list
   // (GY > 1: a group may have fewer than GY lines: run index -1; such a wave only keeps the barriers company)
-  const int ridx = GY > 1 ? list[(item & ~(GY - 1)) + wv] : (list ? list[item] : item);
+  const int ridx = GY > 1 ? list[gBase + wv] : (list ? list[item] : item);
   if (GY > 1 && ridx < 0) {
-    const int n = A.march[list[item & ~(GY - 1)]].len;
+    const int n = A.march[list[gBase]].len;
     for (int t = 0; t < n; ++t) __syncthreads();
     return;
   }
@@ -1158,7 +1166,14 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lagpf(SellView A, t
   const int endOff = lane == 0 ? -1 : 1;
   // (GY > 1: only the group's first / last line has a far neighbour outside the group)
   const bool farM = GY == 1 || wv == 0,
-             farP = GY == 1 || wv == GY - 1 || list[(item & ~(GY - 1)) + min(wv + 1, GY - 1)] < 0;
+             farP = GY == 1 || wv == GY - 1 ||
+                    __builtin_amdgcn_readfirstlane(list[gBase + min(wv + 1, GY - 1)]) < 0;
+  // (GY > 1) a wave at the upper end of its group evaluates its far edge EARLY in the step (its shares wait in
+  // two registers for their turn in the CSR-ordered sums), so that the far row's registers are free for the
+  // NEXT step's far row for most of the step: the one load of the kernel that misses the L2 is then as far
+  // ahead as the prefetch.  A wave at the lower end reloads right after slot 1.  (Groups have two lines or more:
+  // finalize gives single lines to the GY = 1 form.)
+  const bool early4 = GY > 1 && farP && !farM;
   // ---- the prefetch: ids of the wave's first row in the prefetched slots (wave-uniform, one step ahead)
   double *const ldsW = ldsAll + wv * L::kDoubles;
   double *const ldsE = ldsW + L::NB * NFP * 64;
@@ -1201,21 +1216,27 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lagpf(SellView A, t
       E2 = Op::load_edge(P, (long long)(eid[2] & 0x7FFFFFFFu));
     }
     if (GY == 1) {
-      if (act & 2u) ym = Op::load(P, row + D.ko[1]);
-      if (act & 16u) yp = Op::load(P, row + D.ko[4]);
-    } else if (farM) {
-      if (act & 2u) ym = Op::load(P, row + D.ko[1]);
-    } else if (farP) {
-      if (act & 16u) ym = Op::load(P, row + D.ko[4]);
+      if (act & 2u) ym = LAG_FAR(row + D.ko[1]);
+      if (act & 16u) yp = LAG_FAR(row + D.ko[4]);
     }
+#ifdef NG_LAG_NOEND
+    en = prev;
+#else
     if (endLane) en = Op::load(P, row + endOff);
+#endif
   };
   loadB();
+  if (GY > 1) {  // the first step's far row
+    if (farM) { if (act & 2u) ym = LAG_FAR(row + D.ko[1]); }
+    else if (farP) { if (act & 16u) ym = LAG_FAR(row + D.ko[4]); }
+  }
   for (int t = 0; t < gLen; ++t) {
     // ---- (A) this step's prefetch and (B) have landed (and the last step's stores are acknowledged): LDS -> registers
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     asm volatile("" ::: "memory");
+#ifndef NG_LAG_NOBAR
     if (GY > 1) __syncthreads();
+#endif
     const int cur = GY > 1 ? (t & 1) : 0;
     const double *const ldsN = ldsW + cur * NFP * 64;
     Node own;
@@ -1311,8 +1332,26 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lagpf(SellView A, t
       for (int f = 0; f < NF; ++f) pn[f] = src[f * 64 + lane];
       return nb;
     };
-    if (GY == 1 || farM) slot(1, ym);
-    else slot(1, group_row(wv - 1));
+    // (GY > 1) the far edge of a wave at an end of its group, then at once the NEXT step's far row into the
+    // same registers.  ym is not read again in this step on any path: the compiler's wait for it would be a
+    // wait for everything in flight, the prefetch included.
+    double d4 = 0.0, r4 = 0.0;
+    if (GY > 1 && farM) {
+      slot(1, ym);
+      if (t + 1 < gLen && (act & 2u)) ym = LAG_FAR(row + gRowStep + D.ko[1]);
+    } else if (early4) {
+      if (act & 16u) {
+        LAG_EDGE(P, Op::mirrored(E[4], (eid[4] >> 31) != 0), own, ym, lhs, rh);
+        d4 = lhs[0];
+        r4 = rh[0];
+        const long long pos = pos0 + kk(4) * SELL_C;
+        if (SET) LAG_ST(A.vals + pos, lhs[1]);
+        else A.vals[pos] += lhs[1];
+        if (t + 1 < gLen) ym = LAG_FAR(row + gRowStep + D.ko[4]);
+      }
+    }
+    if (GY == 1) slot(1, ym);
+    else if (!farM) slot(1, group_row(wv - 1));
     {
       Node xm;
       const double *po = reinterpret_cast<const double *>(&own), *pe = reinterpret_cast<const double *>(&en);
@@ -1330,8 +1369,9 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lagpf(SellView A, t
       slot(3, xp);
     }
     if (GY == 1) slot(4, yp);
-    else if (farP) slot(4, ym);
-    else slot(4, group_row(wv + 1));
+    else if (early4) {
+      if (act & 16u) { diag += d4; b += r4; }
+    } else if (!farP) slot(4, group_row(wv + 1));  // (farM && farP: no such group, finalize keeps single lines out)
     if (SET) {
       for (int k = 0; k < w; ++k)
         if ((zeroMask >> k) & 1u) A.vals[pos0 + (long long)k * SELL_C] = 0.0;
@@ -1578,18 +1618,29 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
                h->dBurst && h->dMarch && !h->dEdgeOwned) {
       const int nPat = h->nMarchPat, nRest = h->nMarch - h->nMarchPat;
       if (nPat > 0 && lag_kernel(h)) {
-        // NG_ASM_LAG_GROUPS=1: groups of four runs of adjacent lines first (their rows meet in LDS: a quarter
-        // of the far gathers, one barrier per step), then the runs left over.  Measured, not the default:
-        // 256^3 1.014 against 0.973 ms, 512^3 7.19 against 7.51 ms (profiles/r3_lag_ablation.txt).
-        const bool grouped = getenv("NG_ASM_LAG_GROUPS") && atoi(getenv("NG_ASM_LAG_GROUPS")) != 0;
-        // NG_ASM_LAG_PF=1: the variants that prefetch a step's streamed operands into LDS (k_assemble_rows_lagpf)
-        const bool pf = getenv("NG_ASM_LAG_PF") && atoi(getenv("NG_ASM_LAG_PF")) != 0 && h->nEdges >= 64;
+        // The default (round 3): the prefetching kernel on groups of four adjacent lines (k_assemble_rows_lagpf<.., 4>:
+        // 256^3 continuity 0.97 -> 0.89 ms, scalar 1.27 -> 1.15 ms; 512^3 7.55 -> 6.90 / 10.0 -> 9.03 ms).
+        // NG_ASM_LAG_PF=0: no LDS prefetch (k_assemble_rows_lag); NG_ASM_LAG_GROUPS=0: single runs instead of
+        // groups; NG_ASM_LAG_GY=8: groups of eight lines in 512-thread workgroups (measured: slower, 0.93 ms).
+        auto env_on = [](const char *name) { const char *e = getenv(name); return !e || atoi(e) != 0; };
+        const bool grouped = env_on("NG_ASM_LAG_GROUPS");
+        const bool pf = env_on("NG_ASM_LAG_PF") && h->nEdges >= 64;
         const int nG = grouped ? h->nMarchGroups : 0, nS = grouped ? h->nMarchSingles : nPat;
         const int *singles = grouped ? h->dMarchSingles : nullptr;
         if (grouped && pf) {  // (every pattern run in one launch: incomplete groups have idle waves)
-          const int nP = h->nMarchGroupsP;
-          if (set) k_assemble_rows_lagpf<Op, true, 4><<<4 * nP, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, 4 * nP, h->nEdges);
-          else k_assemble_rows_lagpf<Op, false, 4><<<4 * nP, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, 4 * nP, h->nEdges);
+          const int nP = h->nMarchGroupsP, nI = (SELL_C / 64) * nP;  // items: the four quarters of every group
+          if (nI == 0) {
+          } else if (h->marchGY == 8) {
+            if (set) k_assemble_rows_lagpf<Op, true, 8><<<nI, 512, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges);
+            else k_assemble_rows_lagpf<Op, false, 8><<<nI, 512, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges);
+          } else {
+            if (set) k_assemble_rows_lagpf<Op, true, 4><<<nI, 256, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges);
+            else k_assemble_rows_lagpf<Op, false, 4><<<nI, 256, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges);
+          }
+          if (const int n1 = h->nMarchSinglesP) {  // (lines without a neighbour to group with)
+            if (set) k_assemble_rows_lagpf<Op, true, 1><<<n1, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchSinglesP, n1, h->nEdges);
+            else k_assemble_rows_lagpf<Op, false, 1><<<n1, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchSinglesP, n1, h->nEdges);
+          }
         } else if (nG > 0) {
           if (set) k_assemble_rows_lag<Op, true, 4><<<4 * nG, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroups, 4 * nG);
           else k_assemble_rows_lag<Op, false, 4><<<4 * nG, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroups, 4 * nG);

@@ -179,7 +179,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dTags); NG_FREE(h->dDiagPos); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
-  NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dBurst); NG_FREE(h->dMarch); NG_FREE(h->dMarchGroups); NG_FREE(h->dMarchSingles); NG_FREE(h->dMarchGroupsP); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
+  NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dBurst); NG_FREE(h->dMarch); NG_FREE(h->dMarchGroups); NG_FREE(h->dMarchSingles); NG_FREE(h->dMarchGroupsP); NG_FREE(h->dMarchSinglesP); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   for (auto &fd : h->flow) {
     NG_FREE(fd.dTicket); NG_FREE(fd.dChunks); NG_FREE(fd.dRowOf); NG_FREE(fd.dPubOf); NG_FREE(fd.dXch); NG_FREE(fd.dCode); NG_FREE(fd.dSteps); NG_FREE(fd.dSrc); NG_FREE(fd.dVal);
@@ -1038,6 +1038,7 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
       }
       h->nMarchPat = (int)segs.size();
       if (const char *e = getenv("NG_MARCH_XCD")) h->marchXcdRun = std::max(1, atoi(e));
+      if (const char *e = getenv("NG_ASM_LAG_GY")) h->marchGY = atoi(e) == 8 ? 8 : 4;
       h->marchSlices = 0;
       h->marchLongest = 0;
       h->marchLag = !segs.empty();
@@ -1050,7 +1051,7 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
       // first slices lie one, two and three "far offsets" further on (ko[4] = -ko[1] = a whole number of
       // slices: on a lattice the next line of the plane), same length and strides
       {
-        std::vector<int> groups, singles, groupsP;  // groupsP: the same, but incomplete groups are kept and padded with -1
+        std::vector<int> groups, singles, groupsP, singlesP;  // groupsP: the same, but incomplete groups of two or more are kept and padded with -1
         if (h->marchLag) {
           std::unordered_map<int, int> runAt;
           for (int r = 0; r < h->nMarchPat; ++r) runAt[segs[(size_t)r].start] = r;
@@ -1077,15 +1078,18 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
               singles.push_back(r);
             }
           }
+          // (the prefetching kernel's groups: GP = 4 lines, one 256-thread workgroup per quarter of the lines;
+          // NG_ASM_LAG_GY=8: eight lines, 512-thread workgroups)
+          const int GP = h->marchGY;
           std::fill(used.begin(), used.end(), 0);
           for (int r = 0; r < h->nMarchPat; ++r) {
             if (used[(size_t)r]) continue;
             const MarchSeg &g0 = segs[(size_t)r];
             const int up = yoff[2 * (size_t)g0.start + 1], dn = yoff[2 * (size_t)g0.start];
-            int member[4] = {r, -1, -1, -1};
+            int member[8] = {r, -1, -1, -1, -1, -1, -1, -1};
             used[(size_t)r] = 1;
             const bool chain = up > 0 && up % SELL_C == 0 && dn == -up;
-            for (int q = 1; q < 4 && chain; ++q) {
+            for (int q = 1; q < GP && chain; ++q) {
               auto it = runAt.find(g0.start + q * (up / SELL_C));
               if (it == runAt.end() || used[(size_t)it->second]) break;
               const MarchSeg &g = segs[(size_t)it->second];
@@ -1095,12 +1099,20 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
               member[q] = it->second;
               used[(size_t)it->second] = 1;
             }
-            for (int q = 0; q < 4; ++q) groupsP.push_back(member[q]);
+            // (a group of ONE line goes to the kernel's single-run form: a wave with both far rows would need
+            // a second far load in the middle of its step)
+            if (member[1] < 0) singlesP.push_back(r);
+            else
+              for (int q = 0; q < GP; ++q) groupsP.push_back(member[q]);
           }
         }
         h->nMarchGroups = (int)groups.size() / 4;
         h->nMarchSingles = (int)singles.size();
-        h->nMarchGroupsP = (int)groupsP.size() / 4;
+        h->nMarchGroupsP = (int)groupsP.size() / h->marchGY;
+        h->nMarchSinglesP = (int)singlesP.size();
+        NG_HIP(hipMalloc(&h->dMarchSinglesP, sizeof(int) * std::max<size_t>(singlesP.size(), 1)));
+        if (!singlesP.empty())
+          NG_HIP(hipMemcpy(h->dMarchSinglesP, singlesP.data(), sizeof(int) * singlesP.size(), hipMemcpyHostToDevice));
         NG_HIP(hipMalloc(&h->dMarchGroupsP, sizeof(int) * std::max<size_t>(groupsP.size(), 1)));
         if (!groupsP.empty())
           NG_HIP(hipMemcpy(h->dMarchGroupsP, groupsP.data(), sizeof(int) * groupsP.size(), hipMemcpyHostToDevice));

@@ -226,6 +226,9 @@ struct nalu_gpu_linsys {
   int nMarchGroups = 0, nMarchSingles = 0;
   int *dMarchGroupsP = nullptr;  // every pattern run in groups of up to four adjacent lines, -1 = no member (lagpf kernel)
   int nMarchGroupsP = 0;
+  int *dMarchSinglesP = nullptr;  // the pattern runs without a neighbouring line to group with
+  int nMarchSinglesP = 0;
+  int marchGY = 4;               // lines per group of dMarchGroupsP (4 or 8; NG_ASM_LAG_GY)
   bool asmExplicit = false;              // an NG_ASM_* variable chose the assembly kernel   // nSlices (null: maxSliceWidth > BURST_W)
 
   // edges

@@ -138,10 +138,13 @@ SLOT_CASES = [
     ((300, 4, 3), 0.0, 0.0),      # x-lines straddle slices: mixed flagged / computed rows
     ((256, 6, 20), 0.125, 0.9),   # long z-runs for the marching kernel (carried edge over 16 steps)
     ((512, 6, 20), 0.125, 0.9),   # ... with two slices per x-line: the node across the slice boundary is staged too
+    ((256, 13, 7), 0.125, 0.9),   # 11 interior lines: groups of 4 + 4 + 3 (or 8 + 3) adjacent lines
+    ((256, 7, 5), 0.125, 0.9),    # 5 interior lines: a group of four and ONE line left over (the kernel's single-run form)
+    ((256, 3, 6), 0.125, 0.9),    # 1 interior line per plane: no groups at all
 ]
 
 
-@pytest.mark.parametrize("variant", ["default", "row", "NG_ASM_BURST", "NG_ASM_MARCH", "lag_off", "lag_groups", "lag_pf", "lag_pf_groups"])
+@pytest.mark.parametrize("variant", ["default", "row", "NG_ASM_BURST", "NG_ASM_MARCH", "lag_off", "lag_nopf", "lag_groups", "lag_pf", "lag_pf_groups8"])
 @pytest.mark.parametrize("dims,perturb,min_computed", SLOT_CASES)
 def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, perturb, min_computed, variant):
     """default: the automatic choice (the marching kernel where at least half of the slices are in
@@ -153,13 +156,15 @@ def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, pert
         monkeypatch.setenv("NG_ASM_MARCH", "0")
     elif variant == "lag_off":  # round 2's marching kernel (LDS + one barrier per step) instead of the lagged one
         monkeypatch.setenv("NG_ASM_LAG", "0")
-    elif variant == "lag_groups":  # four runs of adjacent lines per workgroup, their rows shared through LDS
-        monkeypatch.setenv("NG_ASM_LAG_GROUPS", "1")
-    elif variant == "lag_pf":  # a step's streamed operands prefetched into LDS one step ahead (direct-to-LDS loads)
-        monkeypatch.setenv("NG_ASM_LAG_PF", "1")
-    elif variant == "lag_pf_groups":  # ... and four adjacent lines per workgroup that read each other's rows from LDS
-        monkeypatch.setenv("NG_ASM_LAG_PF", "1")
-        monkeypatch.setenv("NG_ASM_LAG_GROUPS", "1")
+    elif variant == "lag_nopf":  # round 3's first lagged kernel: no LDS prefetch, single runs
+        monkeypatch.setenv("NG_ASM_LAG_PF", "0")
+        monkeypatch.setenv("NG_ASM_LAG_GROUPS", "0")
+    elif variant == "lag_groups":  # ... four runs of adjacent lines per workgroup, their rows shared through LDS
+        monkeypatch.setenv("NG_ASM_LAG_PF", "0")
+    elif variant == "lag_pf":  # a step's streamed operands prefetched into LDS one step ahead, single runs
+        monkeypatch.setenv("NG_ASM_LAG_GROUPS", "0")
+    elif variant == "lag_pf_groups8":  # the default kernel on groups of eight lines (512-thread workgroups) instead of four
+        monkeypatch.setenv("NG_ASM_LAG_GY", "8")
     elif variant != "default":
         monkeypatch.setenv(variant, "1")
     c = BenchCase(G, oracle, dims, perturb)
@@ -173,8 +178,8 @@ def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, pert
     lag = 5 if li["march_runs"] > 0 else 4
     assert li["assembly_variant"] == {"default": lag if marching else 0, "row": 0, "NG_ASM_BURST": 3,
                                       "NG_ASM_MARCH": lag, "lag_off": 4 if marching else 0,
-                                      "lag_groups": lag if marching else 0, "lag_pf": lag if marching else 0,
-                                      "lag_pf_groups": lag if marching else 0}[variant], li
+                                      "lag_nopf": lag if marching else 0, "lag_groups": lag if marching else 0,
+                                      "lag_pf": lag if marching else 0, "lag_pf_groups8": lag if marching else 0}[variant], li
     if dims == (256, 6, 20):  # 4 interior lines x 18 interior planes: runs of 16 + 2 slices
         assert marching and li["march_longest"] == 16 and li["march_slices"] == 72 and li["march_runs"] == 8, li
     if dims == (512, 6, 20):  # ... two slices per line
