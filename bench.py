@@ -36,15 +36,15 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 def pmc_traffic(dims):
     """HBM bytes per launch of the hot kernels from the committed rocprofv3 --pmc passes
-    (profiles/r3_traffic.json, collected by scripts/r3_profile.sh on the 256^3 and 512^3 boxes):
+    (profiles/r3b_traffic.json, collected by scripts/r3_profile.sh on the 256^3 and 512^3 boxes):
     counters cannot be collected inside this run, so `traffic` is only reported for the boxes they
     were measured on.  Returns {kernel: record} and the source file."""
     try:
-        d = json.load(open(os.path.join(HERE, "profiles", "r3_traffic.json")))
+        d = json.load(open(os.path.join(HERE, "profiles", "r3b_traffic.json")))
     except OSError:
         return {}, None
     if dims[0] == dims[1] == dims[2] and str(dims[0]) in d.get("boxes", {}):
-        return d["boxes"][str(dims[0])], "profiles/r3_traffic.json"
+        return d["boxes"][str(dims[0])], "profiles/r3b_traffic.json"
     return {}, None
 
 
@@ -470,8 +470,8 @@ def main():
         op = "ScalOp" if scalar else "ContOp"
         asm_kernel = f"k_assemble_rows<{op}> ({a.mode})"
         asm_parts = [f"k_assemble_rows<{op}>"]
-        if a.mode == "rows" and layout["assembly_variant"] in (4, 5) and (layout["assembly_variant"] == 5 or not scalar):
-            main = "k_assemble_rows_lag" if layout["assembly_variant"] == 5 else "k_assemble_rows_march"
+        if a.mode == "rows" and layout["assembly_variant"] in (4, 5, 6) and (layout["assembly_variant"] >= 5 or not scalar):
+            main = {4: "k_assemble_rows_march", 5: "k_assemble_rows_lag", 6: "k_assemble_rows_lagpf"}[layout["assembly_variant"]]
             asm_kernel = (f"{main}<{op}> over {layout['march_runs']} runs of slices "
                           f"({layout['march_slices']} of {layout['n_slices']} slices) + k_assemble_rows_burst for the rest")
             asm_parts = [f"{main}<{op}>", f"k_assemble_rows_burst<{op}>"]

@@ -138,7 +138,8 @@ typedef struct {
   int64_t rows_computed_tags;    /* owned rows whose edge ids are computed (row-gather assembly) */
   int assembly_variant;          /* row-gather kernel in force for the continuity operator: 0 row kernel,
                                     1 entries, 2 ordered, 3 burst, 4 marching, 5 lagged marching without
-                                    barriers (default where it applies) */
+                                    barriers, 6 the lagged kernel with its streamed operands prefetched into
+                                    LDS on groups of adjacent lines (default where it applies) */
   int xcd_run;                   /* slices per XCD run of the row-kernel schedule */
   int64_t march_runs;            /* runs of slices the marching assembly kernel walks (0: none) */
   int64_t march_slices;          /* slices in those runs */

@@ -1271,13 +1271,16 @@ __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_
       }
     }
     // ---- (E) the next step's prefetch, as early as the region is free
-    if (t + 1 < gLen) {
+    auto issue_prefetch = [&]() {
+      if (t + 1 < gLen) {
 #pragma unroll
-      for (int k = 0; k < NS; ++k) pfId[k] += pfStep[k];
-      prefetch(rowW + (t + 1) * gRowStep, GY > 1 ? (cur ^ 1) : 0);
-    }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < NS; ++k) pfId[k] += pfStep[k];
+        prefetch(rowW + (t + 1) * gRowStep, GY > 1 ? (cur ^ 1) : 0);
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    issue_prefetch();
     double diag = 0.0, b = 0.0;
     double lhs[4], rh[2];
     if (act & 1u) LAG_EDGE(P, Op::mirrored(E[0], (eid[0] >> 31) != 0), own, prev, lhs, rh);
@@ -1622,9 +1625,8 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
         // 256^3 continuity 0.97 -> 0.89 ms, scalar 1.27 -> 1.15 ms; 512^3 7.55 -> 6.90 / 10.0 -> 9.03 ms).
         // NG_ASM_LAG_PF=0: no LDS prefetch (k_assemble_rows_lag); NG_ASM_LAG_GROUPS=0: single runs instead of
         // groups; NG_ASM_LAG_GY=8: groups of eight lines in 512-thread workgroups (measured: slower, 0.93 ms).
-        auto env_on = [](const char *name) { const char *e = getenv(name); return !e || atoi(e) != 0; };
-        const bool grouped = env_on("NG_ASM_LAG_GROUPS");
-        const bool pf = env_on("NG_ASM_LAG_PF") && h->nEdges >= 64;
+        const bool grouped = lag_grouped();
+        const bool pf = lag_prefetch(h);
         const int nG = grouped ? h->nMarchGroups : 0, nS = grouped ? h->nMarchSingles : nPat;
         const int *singles = grouped ? h->dMarchSingles : nullptr;
         if (grouped && pf) {  // (every pattern run in one launch: incomplete groups have idle waves)

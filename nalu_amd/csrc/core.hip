@@ -1233,7 +1233,7 @@ extern "C" int nalu_gpu_get_layout_info(nalu_gpu_linsys *h, nalu_gpu_layout_info
   info->max_slice_width = h->maxSliceWidth;
   info->rows_computed_columns = cc;
   info->rows_computed_tags = ct;
-  info->assembly_variant = (march_by_default(h) || h->asmVariant == 4) ? (lag_kernel(h) ? 5 : 4) : h->asmVariant;
+  info->assembly_variant = (march_by_default(h) || h->asmVariant == 4) ? (lag_kernel(h) ? (lag_prefetch(h) ? 6 : 5) : 4) : h->asmVariant;
   info->march_runs = h->nMarchPat;
   info->march_slices = h->marchSlices;
   info->march_longest = h->marchLongest;

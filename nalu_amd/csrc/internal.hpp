@@ -458,6 +458,17 @@ inline bool lag_kernel(const nalu_gpu_linsys *h)
   return !(e && atoi(e) == 0);
 }
 
+// ... by default in its prefetching form (k_assemble_rows_lagpf: a step's streamed operands requested one step
+// ahead by direct-to-LDS loads; NG_ASM_LAG_PF=0 turns it off) on groups of adjacent lines (NG_ASM_LAG_GROUPS=0:
+// single runs)
+inline bool env_not_zero(const char *name)
+{
+  const char *e = getenv(name);
+  return !e || atoi(e) != 0;
+}
+inline bool lag_prefetch(const nalu_gpu_linsys *h) { return env_not_zero("NG_ASM_LAG_PF") && h->nEdges >= 64; }
+inline bool lag_grouped() { return env_not_zero("NG_ASM_LAG_GROUPS"); }
+
 void timer_begin(nalu_gpu_linsys *h, int which);
 void timer_end(nalu_gpu_linsys *h, int which);
 int materialize_zero(nalu_gpu_linsys *h);

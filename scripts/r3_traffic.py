@@ -5,6 +5,7 @@ import collections, csv, glob, json, re, sys
 
 KERNELS = {  # name in the JSON -> substrings that all must occur in the (demangled) kernel name
     "k_spmv<DOT>": ("k_spmv<true, false>",), "k_spmv<DINV>": ("k_spmv<false, true>",), "k_spmv": ("k_spmv<false, false>",),
+    "k_assemble_rows_lagpf<ContOp>": ("k_assemble_rows_lagpf<", "ContOp,"), "k_assemble_rows_lagpf<ScalOp>": ("k_assemble_rows_lagpf<", "ScalOp,"),
     "k_assemble_rows_lag<ContOp>": ("k_assemble_rows_lag<", "ContOp,"), "k_assemble_rows_burst<ContOp>": ("k_assemble_rows_burst<", "ContOp,"),
     "k_assemble_rows_lag<ScalOp>": ("k_assemble_rows_lag<", "ScalOp,"), "k_assemble_rows_burst<ScalOp>": ("k_assemble_rows_burst<", "ScalOp,"),
     "k_assemble_rows_march<ContOp>": ("k_assemble_rows_march<", "ContOp,"), "k_assemble_rows<ScalOp>": ("k_assemble_rows<", "ScalOp,"),

@@ -174,12 +174,14 @@ def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, pert
     n = c.S.n_owned
     # what makes the marching kernel the automatic choice
     marching = li["march_slices"] * 2 >= li["n_slices"] and li["march_slices"] >= 4 * li["march_runs"]
-    # (5: the lagged, barrier-free marching kernel -- every run of these lattices qualifies for it)
-    lag = 5 if li["march_runs"] > 0 else 4
-    assert li["assembly_variant"] == {"default": lag if marching else 0, "row": 0, "NG_ASM_BURST": 3,
-                                      "NG_ASM_MARCH": lag, "lag_off": 4 if marching else 0,
+    # (5: the lagged, barrier-free marching kernel -- every run of these lattices qualifies for it; 6: its
+    # prefetching form, the default)
+    lag, lagpf = (5, 6) if li["march_runs"] > 0 else (4, 4)
+    assert li["assembly_variant"] == {"default": lagpf if marching else 0, "row": 0, "NG_ASM_BURST": 3,
+                                      "NG_ASM_MARCH": lagpf, "lag_off": 4 if marching else 0,
                                       "lag_nopf": lag if marching else 0, "lag_groups": lag if marching else 0,
-                                      "lag_pf": lag if marching else 0, "lag_pf_groups8": lag if marching else 0}[variant], li
+                                      "lag_pf": lagpf if marching else 0,
+                                      "lag_pf_groups8": lagpf if marching else 0}[variant], li
     if dims == (256, 6, 20):  # 4 interior lines x 18 interior planes: runs of 16 + 2 slices
         assert marching and li["march_longest"] == 16 and li["march_slices"] == 72 and li["march_runs"] == 8, li
     if dims == (512, 6, 20):  # ... two slices per line
@@ -229,7 +231,7 @@ def test_suggested_edge_order_reaches_the_fast_paths(G, torch, oracle, dims, per
     d = c.dev(torch)
     g = c.gpu_system(G)
     li, lr = g.layout_info(), ref.gpu_system(G).layout_info()
-    assert li["assembly_variant"] == lr["assembly_variant"] and (dims != (256, 6, 20) or lr["assembly_variant"] == 5)
+    assert li["assembly_variant"] == lr["assembly_variant"] and (dims != (256, 6, 20) or lr["assembly_variant"] == 6)
     if dims[0] % 256 == 0:  # one x-line (or half of one) per slice: the same fast paths, row for row
         for k in ("rows_computed_tags", "rows_computed_columns", "march_slices", "march_runs"):
             assert li[k] == lr[k], (k, li, lr)
