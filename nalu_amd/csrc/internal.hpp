@@ -133,6 +133,7 @@ struct SolverScalars {
   double rz, rr0, r0norm, alpha, beta, tol, hn;
   int iter, done, j, maxIter, histCap, pad;
   double *alphaHist;  // CG: alpha of every iteration (the x update is applied in batches)
+  double aux[8];      // BiCGStab / TFQMR recurrences (solve.hip)
 };
 
 }  // namespace nalu_gpu

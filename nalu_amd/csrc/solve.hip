@@ -1370,13 +1370,27 @@ int solve_gmres(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int check
 // reg_tests/test_files/edgeHybridFluids/edgeHybridFluids.i:10).  Right-preconditioned like the
 // rest (src/LinearSolver.C:105); Belos' iteration classes are Trilinos code, so the published
 // algorithms are restated (van der Vorst; Freund's TFQMR as in Saad, Alg. 7.8): parity
-// unpinned.  They are the seldom-used methods: the scalar recurrences run on the host (one
-// small device-to-host copy per dot product), the vector work in the kernels below.
+// unpinned.  Device resident since round 3, like cg and gmres: the scalar recurrences run in
+// one-thread kernels behind the (all-)reduced dot products, the vector kernels read their
+// coefficients from the device scalars, every kernel checks the device `done` flag and the host
+// polls it every check_every iterations -- no scalar read-back per dot product any more.  The
+// arithmetic (operations and their order, the partial-sum layout of the dot products) is the
+// host-driven loop's of round 2, so the histories are the same bit for bit.
+
+// a coefficient of the vector kernels below: sign * (*ptr), or sign alone (ptr == nullptr)
+struct Coef {
+  const double *ptr;
+  double sign;
+  __device__ __forceinline__ double get() const { return ptr ? sign * *ptr : sign; }
+};
 
 // out = a x + b y + c z (null y / z are skipped; out may alias any of them)
-__global__ __launch_bounds__(256) void k_lin3(long long n, double a, const double *x, double b, const double *y,
-                                               double c, const double *z, double *out)
+__global__ __launch_bounds__(256) void k_lin3(long long n, const SolverScalars *__restrict__ sc, Coef ca,
+                                               const double *x, Coef cb, const double *y, Coef cc, const double *z,
+                                               double *out)
 {
+  if (sc->done) return;
+  const double a = ca.get(), b = y ? cb.get() : 0.0, c = z ? cc.get() : 0.0;
   GRID_STRIDE(i, n) {
     double v = a * x[i];
     if (y) v = v + b * y[i];
@@ -1385,60 +1399,161 @@ __global__ __launch_bounds__(256) void k_lin3(long long n, double a, const doubl
   }
 }
 
-// p = r + beta (p - omega v)
-__global__ __launch_bounds__(256) void k_bicg_p(long long n, double beta, double omega, const double *r,
+// p = r + beta (p - omega v)   (beta = sc->beta, omega = sc->hn)
+__global__ __launch_bounds__(256) void k_bicg_p(long long n, const SolverScalars *__restrict__ sc, const double *r,
                                                  const double *v, double *p)
 {
+  if (sc->done) return;
+  const double beta = sc->beta, omega = sc->hn;
   GRID_STRIDE(i, n) p[i] = r[i] + beta * (p[i] - omega * v[i]);
 }
 
 // v = beta (au + beta v)
-__global__ __launch_bounds__(256) void k_tfqmr_v(long long n, double beta, const double *au, double *v)
+__global__ __launch_bounds__(256) void k_tfqmr_v(long long n, const SolverScalars *__restrict__ sc, const double *au,
+                                                  double *v)
 {
+  if (sc->done) return;
+  const double beta = sc->beta;
   GRID_STRIDE(i, n) v[i] = beta * (au[i] + beta * v[i]);
 }
 
-__global__ __launch_bounds__(256) void k_scale_by(long long n, const double *dinv, const double *r, double *z)
+__global__ __launch_bounds__(256) void k_scale_by(long long n, const SolverScalars *__restrict__ sc,
+                                                   const double *dinv, const double *r, double *z)
 {
+  if (sc && sc->done) return;
   GRID_STRIDE(i, n) z[i] = dinv[i] * r[i];
 }
 
-struct HostKrylov {
+// ---- scalar recurrences (one thread each).  SolverScalars: rz = rho of the previous iteration,
+// alpha, beta, hn = omega (BiCGStab); aux[0] = rho of this iteration (BiCGStab) / rho (TFQMR),
+// aux[1] = tau, aux[2] = theta, aux[3] = eta, aux[4] = theta^2 eta / alpha (TFQMR)
+__global__ void k_kry_scal_init(SolverScalars *sc, const double *red, double *hist, double tol, int maxIter,
+                                int histCap)
+{
+  sc->alphaHist = nullptr;
+  sc->rr0 = red[0];
+  sc->r0norm = sqrt(red[0]);
+  sc->rz = 1.0;
+  sc->alpha = 1.0;
+  sc->hn = 1.0;
+  sc->beta = 0.0;
+  sc->tol = tol;
+  sc->iter = 0;
+  sc->j = 0;
+  sc->maxIter = maxIter;
+  sc->histCap = histCap;
+  sc->done = (sc->r0norm == 0.0 || maxIter <= 0) ? 1 : 0;
+  for (int i = 0; i < 8; ++i) sc->aux[i] = 0.0;
+  sc->aux[0] = red[0];        // TFQMR: rho = (r*, w) = (b, b)
+  sc->aux[1] = sc->r0norm;    // TFQMR: tau
+  if (histCap > 0) hist[0] = 1.0;
+}
+
+__global__ void k_bi_scal_beta(SolverScalars *sc, const double *red)
+{
+  if (sc->done) return;
+  const double rhoNew = red[0];
+  sc->beta = (rhoNew / sc->rz) * (sc->alpha / sc->hn);
+  sc->aux[0] = rhoNew;
+}
+
+__global__ void k_bi_scal_alpha(SolverScalars *sc, const double *red)
+{
+  if (sc->done) return;
+  sc->alpha = sc->aux[0] / red[0];
+}
+
+__global__ void k_bi_scal_omega(SolverScalars *sc, const double *red)
+{
+  if (sc->done) return;
+  sc->hn = red[0] / red[1];
+}
+
+__global__ void k_bi_scal_test(SolverScalars *sc, const double *red, double *hist)
+{
+  if (sc->done) return;
+  sc->rz = sc->aux[0];
+  sc->iter += 1;
+  const double rel = sqrt(red[0]) / sc->r0norm;
+  if (sc->iter < sc->histCap) hist[sc->iter] = rel;
+  if (rel <= sc->tol || sc->iter >= sc->maxIter) sc->done = 1;
+}
+
+__global__ void k_tf_scal_alpha(SolverScalars *sc, const double *red)
+{
+  if (sc->done) return;
+  sc->alpha = sc->aux[0] / red[0];
+  sc->aux[4] = sc->aux[2] * sc->aux[2] * sc->aux[3] / sc->alpha;
+}
+
+__global__ void k_tf_scal_theta(SolverScalars *sc, const double *red)
+{
+  if (sc->done) return;
+  const double theta = sqrt(red[0]) / sc->aux[1];
+  const double c = 1.0 / sqrt(1.0 + theta * theta);
+  sc->aux[2] = theta;
+  sc->aux[1] = sc->aux[1] * theta * c;
+  sc->aux[3] = c * c * sc->alpha;
+  sc->aux[4] = sc->aux[2] * sc->aux[2] * sc->aux[3] / sc->alpha;  // (the next half step's, same alpha)
+}
+
+// end of a TFQMR iteration: beta and the new rho, then the residual estimate and the test.  The vector
+// work behind it only prepares the next iteration, so a stop here skips it.
+__global__ void k_tf_scal_beta_test(SolverScalars *sc, const double *red, double *hist)
+{
+  if (sc->done) return;
+  const double rhoNew = red[0];
+  sc->beta = rhoNew / sc->aux[0];
+  sc->aux[0] = rhoNew;
+  sc->iter += 1;
+  const double rel = sqrt(2.0 * sc->iter + 1.0) * sc->aux[1] / sc->r0norm;
+  if (sc->iter < sc->histCap) hist[sc->iter] = rel;
+  if (rel <= sc->tol || sc->iter >= sc->maxIter) sc->done = 1;
+}
+
+// the vector side of both loops: kernels behind the done flag, dot products into the reduce buffer
+struct DevKrylov {
   nalu_gpu_linsys *h;
   long long n;
   int vb, precond;
-  int dots(int k, const double *const *a, const double *const *b, double *out)
+  const SolverScalars *sc() const { return h->dScal; }
+  Coef one() const { return Coef{nullptr, 1.0}; }
+  Coef coef(size_t off, double sign) const { return Coef{(const double *)((const char *)h->dScal + off), sign}; }
+  Coef alpha(double sign = 1.0) const { return coef(offsetof(SolverScalars, alpha), sign); }
+  Coef beta(double sign = 1.0) const { return coef(offsetof(SolverScalars, beta), sign); }
+  Coef omega(double sign = 1.0) const { return coef(offsetof(SolverScalars, hn), sign); }
+  Coef aux(int i, double sign = 1.0) const { return coef(offsetof(SolverScalars, aux) + sizeof(double) * i, sign); }
+  // k dot products -> h->dReduce[0..k) (all-reduced); the first may run before the done flag exists
+  int dots(int k, const double *const *a, const double *const *b, bool useDone = true)
   {
-    for (int i = 0; i < k; ++i)
-      k_dot<<<vb, 256, 0, h->stream>>>(n, a[i], b[i], h->dPartials + (size_t)i * MAX_BLOCKS);
+    for (int i = 0; i < k; ++i) {
+      if (useDone) k_dot_done<<<vb, 256, 0, h->stream>>>(n, h->dScal, a[i], b[i], h->dPartials + (size_t)i * MAX_BLOCKS);
+      else k_dot<<<vb, 256, 0, h->stream>>>(n, a[i], b[i], h->dPartials + (size_t)i * MAX_BLOCKS);
+    }
     NG_HIP(hipGetLastError());
-    NG_TRY(finish_reduction(h, k, vb));
-    double *pin = (double *)((char *)h->hPinned + 2048);
-    NG_HIP(hipMemcpyAsync(pin, h->dReduce, sizeof(double) * k, hipMemcpyDeviceToHost, h->stream));
-    NG_HIP(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < k; ++i) out[i] = pin[i];
-    return NALU_GPU_OK;
+    return finish_reduction(h, k, vb);
   }
-  int dot1(const double *a, const double *b, double *out) { return dots(1, &a, &b, out); }
+  int dot1(const double *a, const double *b, bool useDone = true) { return dots(1, &a, &b, useDone); }
   // z = M^-1 r (z is a column-space vector: it is multiplied by A next)
-  int prec(const double *r, double *z)
+  int prec(const double *r, double *z, bool useDone = true)
   {
     if (precond == NALU_GPU_PRECOND_NONE || precond == NALU_GPU_PRECOND_JACOBI) {
-      k_scale_by<<<vb, 256, 0, h->stream>>>(n, h->dDinv, r, z);  // (dinv = 1 without a preconditioner)
+      k_scale_by<<<vb, 256, 0, h->stream>>>(n, useDone ? h->dScal : nullptr, h->dDinv, r, z);  // (dinv = 1 without a preconditioner)
       NG_HIP(hipGetLastError());
       return NALU_GPU_OK;
     }
-    return apply_general(h, precond, r, z, false);
+    return apply_general(h, precond, r, z, useDone);
   }
-  int amul(double *x, double *y)
+  int amul(double *x, double *y, bool useDone = true)
   {
     int sb = 0;
-    return spmv_with_halo<false, false>(h, x, y, false, &sb);
+    return spmv_with_halo<false, false>(h, x, y, useDone, &sb);
   }
-  void lin3(double a, const double *x, double b, const double *y, double c, const double *z, double *out)
+  void lin3(Coef a, const double *x, Coef b, const double *y, Coef c, const double *z, double *out)
   {
-    k_lin3<<<vb, 256, 0, h->stream>>>(n, a, x, b, y, c, z, out);
+    k_lin3<<<vb, 256, 0, h->stream>>>(n, h->dScal, a, x, b, y, c, z, out);
   }
+  void lin2(Coef a, const double *x, Coef b, const double *y, double *out) { lin3(a, x, b, y, one(), nullptr, out); }
 };
 
 int ensure_kry(nalu_gpu_linsys *h, int count)
@@ -1454,30 +1569,12 @@ int ensure_kry(nalu_gpu_linsys *h, int count)
   return NALU_GPU_OK;
 }
 
-// iteration count / history go through the device scalars like the other methods' (read back by
-// nalu_gpu_solve)
-__global__ void k_host_scal_store(SolverScalars *sc, int iter, int histCap)
-{
-  sc->iter = iter;
-  sc->done = 1;
-  sc->histCap = histCap;
-}
-
-int store_host_history(nalu_gpu_linsys *h, const std::vector<double> &hist, int iters)
-{
-  const int nh = std::min((int)hist.size(), h->histCap);
-  NG_HIP(hipMemcpyAsync(h->dHist, hist.data(), sizeof(double) * nh, hipMemcpyHostToDevice, h->stream));
-  k_host_scal_store<<<1, 1, 0, h->stream>>>(h->dScal, iters, h->histCap);
-  NG_HIP(hipStreamSynchronize(h->stream));  // hist is a host temporary
-  return NALU_GPU_OK;
-}
-
-int solve_bicgstab(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg)
+int solve_bicgstab(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEvery)
 {
   const long long n = h->nOwned;
   const size_t ld = (size_t)std::max(h->nCols, 1);
   NG_TRY(ensure_kry(h, 8));
-  HostKrylov K{h, n, vec_grid(n), cfg->precond};
+  DevKrylov K{h, n, vec_grid(n), cfg->precond};
   double *r = h->dKry, *rh = r + ld, *p = rh + ld, *v = p + ld, *sv = v + ld, *t = sv + ld, *y = t + ld, *z = y + ld;
   double *x = h->dX;
   const size_t bytes = sizeof(double) * (size_t)n;
@@ -1486,45 +1583,43 @@ int solve_bicgstab(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg)
   NG_HIP(hipMemcpyAsync(rh, h->dRhs, bytes, hipMemcpyDeviceToDevice, h->stream));
   NG_HIP(hipMemsetAsync(p, 0, bytes, h->stream));
   NG_HIP(hipMemsetAsync(v, 0, bytes, h->stream));
-  std::vector<double> hist(1, 1.0);
-  double rr0 = 0.0;
-  NG_TRY(K.dot1(r, r, &rr0));
-  const double r0 = std::sqrt(rr0);
-  int iters = 0;
-  double rhoOld = 1.0, alpha = 1.0, omega = 1.0;
-  while (r0 != 0.0 && iters < cfg->max_iterations) {
-    double rhoNew = 0.0, rhv = 0.0, d2[2] = {0.0, 0.0}, rr = 0.0;
-    NG_TRY(K.dot1(rh, r, &rhoNew));
-    const double beta = (rhoNew / rhoOld) * (alpha / omega);
-    k_bicg_p<<<K.vb, 256, 0, h->stream>>>(n, beta, omega, r, v, p);
+  NG_TRY(K.dot1(r, r, false));
+  k_kry_scal_init<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist, cfg->tolerance, cfg->max_iterations,
+                                          h->histCap);
+  SolverScalars sc;
+  for (int it = 0; it < cfg->max_iterations; ++it) {
+    NG_TRY(K.dot1(rh, r));
+    k_bi_scal_beta<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
+    k_bicg_p<<<K.vb, 256, 0, h->stream>>>(n, h->dScal, r, v, p);
     NG_TRY(K.prec(p, y));
     NG_TRY(K.amul(y, v));
-    NG_TRY(K.dot1(rh, v, &rhv));
-    alpha = rhoNew / rhv;
-    K.lin3(1.0, r, -alpha, v, 0.0, nullptr, sv);  // s = r - alpha v
+    NG_TRY(K.dot1(rh, v));
+    k_bi_scal_alpha<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
+    K.lin2(K.one(), r, K.alpha(-1.0), v, sv);  // s = r - alpha v
     NG_TRY(K.prec(sv, z));
     NG_TRY(K.amul(z, t));
     const double *a2[2] = {t, t}, *b2[2] = {sv, t};
-    NG_TRY(K.dots(2, a2, b2, d2));
-    omega = d2[0] / d2[1];
-    K.lin3(1.0, x, alpha, y, omega, z, x);         // x = x + alpha y + omega z
-    K.lin3(1.0, sv, -omega, t, 0.0, nullptr, r);  // r = s - omega t
-    rhoOld = rhoNew;
-    ++iters;
-    NG_TRY(K.dot1(r, r, &rr));
-    const double rel = std::sqrt(rr) / r0;
-    hist.push_back(rel);
-    if (rel <= cfg->tolerance) break;
+    NG_TRY(K.dots(2, a2, b2));
+    k_bi_scal_omega<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
+    K.lin3(K.one(), x, K.alpha(), y, K.omega(), z, x);  // x = x + alpha y + omega z
+    K.lin2(K.one(), sv, K.omega(-1.0), t, r);            // r = s - omega t
+    NG_TRY(K.dot1(r, r));
+    k_bi_scal_test<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist);
+    NG_HIP(hipGetLastError());
+    if ((it + 1) % checkEvery == 0 && it + 1 < cfg->max_iterations) {
+      NG_TRY(read_scalars(h, &sc));
+      if (sc.done) break;
+    }
   }
-  return store_host_history(h, hist, iters);
+  return NALU_GPU_OK;
 }
 
-int solve_tfqmr(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg)
+int solve_tfqmr(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, int checkEvery)
 {
   const long long n = h->nOwned;
   const size_t ld = (size_t)std::max(h->nCols, 1);
   NG_TRY(ensure_kry(h, 8));
-  HostKrylov K{h, n, vec_grid(n), cfg->precond};
+  DevKrylov K{h, n, vec_grid(n), cfg->precond};
   double *w = h->dKry, *u = w + ld, *v = u + ld, *d = v + ld, *au = d + ld, *rs = au + ld, *ys = rs + ld, *z = ys + ld;
   double *x = h->dX;
   const size_t bytes = sizeof(double) * (size_t)n;
@@ -1534,60 +1629,48 @@ int solve_tfqmr(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg)
   NG_HIP(hipMemcpyAsync(rs, h->dRhs, bytes, hipMemcpyDeviceToDevice, h->stream));
   NG_HIP(hipMemsetAsync(d, 0, bytes, h->stream));
   NG_HIP(hipMemsetAsync(ys, 0, bytes, h->stream));
-  std::vector<double> hist(1, 1.0);
-  double rho = 0.0;
-  NG_TRY(K.dot1(rs, w, &rho));
-  const double r0 = std::sqrt(rho);
-  int iters = 0;
-  if (r0 != 0.0) {
-    NG_TRY(K.prec(u, z));
-    NG_TRY(K.amul(z, v));  // v = A M^-1 u
-    NG_HIP(hipMemcpyAsync(au, v, bytes, hipMemcpyDeviceToDevice, h->stream));
-  }
-  double tau = r0, theta = 0.0, eta = 0.0, alpha = 0.0;
-  while (r0 != 0.0 && iters < cfg->max_iterations) {
+  NG_TRY(K.dot1(rs, w, false));
+  k_kry_scal_init<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist, cfg->tolerance, cfg->max_iterations,
+                                          h->histCap);
+  NG_TRY(K.prec(u, z));
+  NG_TRY(K.amul(z, v));  // v = A M^-1 u
+  K.lin2(K.one(), v, K.one(), nullptr, au);
+  SolverScalars sc;
+  for (int it = 0; it < cfg->max_iterations; ++it) {
     for (int half = 0; half < 2; ++half) {
       if (half == 0) {
-        double vr = 0.0;
-        NG_TRY(K.dot1(v, rs, &vr));
-        alpha = rho / vr;
+        NG_TRY(K.dot1(v, rs));
+        k_tf_scal_alpha<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
       } else {
-        K.lin3(1.0, u, -alpha, v, 0.0, nullptr, u);
+        K.lin2(K.one(), u, K.alpha(-1.0), v, u);
         NG_TRY(K.prec(u, z));
         NG_TRY(K.amul(z, au));
       }
-      K.lin3(1.0, w, -alpha, au, 0.0, nullptr, w);
-      const double dfac = theta * theta * eta / alpha;
-      K.lin3(1.0, u, dfac, d, 0.0, nullptr, d);
-      double ww = 0.0;
-      NG_TRY(K.dot1(w, w, &ww));
-      theta = std::sqrt(ww) / tau;
-      const double c = 1.0 / std::sqrt(1.0 + theta * theta);
-      tau = tau * theta * c;
-      eta = c * c * alpha;
-      K.lin3(1.0, ys, eta, d, 0.0, nullptr, ys);
+      K.lin2(K.one(), w, K.alpha(-1.0), au, w);
+      K.lin2(K.one(), u, K.aux(4), d, d);  // d = u + (theta^2 eta / alpha) d
+      NG_TRY(K.dot1(w, w));
+      k_tf_scal_theta<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce);
+      K.lin2(K.one(), ys, K.aux(3), d, ys);  // y += eta d
       if (half == 1) {
-        double rhoNew = 0.0;
-        NG_TRY(K.dot1(rs, w, &rhoNew));
-        const double beta = rhoNew / rho;
-        rho = rhoNew;
-        K.lin3(1.0, w, beta, u, 0.0, nullptr, u);
-        k_tfqmr_v<<<K.vb, 256, 0, h->stream>>>(n, beta, au, v);
+        NG_TRY(K.dot1(rs, w));
+        k_tf_scal_beta_test<<<1, 1, 0, h->stream>>>(h->dScal, h->dReduce, h->dHist);
+        K.lin2(K.one(), w, K.beta(), u, u);
+        k_tfqmr_v<<<K.vb, 256, 0, h->stream>>>(n, h->dScal, au, v);
         NG_TRY(K.prec(u, z));
         NG_TRY(K.amul(z, au));
-        K.lin3(1.0, au, 1.0, v, 0.0, nullptr, v);
+        K.lin2(K.one(), au, K.one(), v, v);
       }
     }
-    ++iters;
-    const double rel = std::sqrt(2.0 * iters + 1.0) * tau / r0;
-    hist.push_back(rel);
-    if (rel <= cfg->tolerance) break;
+    NG_HIP(hipGetLastError());
+    if ((it + 1) % checkEvery == 0 && it + 1 < cfg->max_iterations) {
+      NG_TRY(read_scalars(h, &sc));
+      if (sc.done) break;
+    }
   }
-  if (r0 != 0.0) {
-    NG_TRY(K.prec(ys, z));
-    NG_HIP(hipMemcpyAsync(x, z, bytes, hipMemcpyDeviceToDevice, h->stream));
-  }
-  return store_host_history(h, hist, iters);
+  // x = M^-1 y (the loop has stopped: no done check)
+  NG_TRY(K.prec(ys, z, false));
+  NG_HIP(hipMemcpyAsync(x, z, bytes, hipMemcpyDeviceToDevice, h->stream));
+  return NALU_GPU_OK;
 }
 
 }  // namespace
@@ -1778,8 +1861,8 @@ static int solve_once(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, dou
   const auto t1 = std::chrono::steady_clock::now();
 
   timer_begin(h, NALU_GPU_T_SOLVE);
-  if (cfg->method == NALU_GPU_METHOD_BICGSTAB) NG_TRY(solve_bicgstab(h, cfg));
-  else if (cfg->method == NALU_GPU_METHOD_TFQMR) NG_TRY(solve_tfqmr(h, cfg));
+  if (cfg->method == NALU_GPU_METHOD_BICGSTAB) NG_TRY(solve_bicgstab(h, cfg, checkEvery));
+  else if (cfg->method == NALU_GPU_METHOD_TFQMR) NG_TRY(solve_tfqmr(h, cfg, checkEvery));
   else if (cfg->method == NALU_GPU_METHOD_CG &&
       (cfg->precond == NALU_GPU_PRECOND_SGS || cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV ||
        cfg->precond == NALU_GPU_PRECOND_MT_SGS))
