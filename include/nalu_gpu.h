@@ -40,7 +40,14 @@ enum {
   NALU_GPU_SCATTER_ATOMIC = 2   /* edge-parallel, fp64 atomics on diag/rhs: NOT bit-reproducible */
 };
 
-/* Belos solver names of src/LinearSolverConfig.C:34-55 as the regression inputs use them */
+/* Belos solver names of src/LinearSolverConfig.C:34-55 as the regression inputs use them.  All four run as
+ * device-resident loops (scalar recurrences on the device, the host polls a done flag every check_every
+ * iterations).  Residual histories against the CPU oracle: cg / gmres <= 1e-10 whatever the summation order
+ * of the dot products; biCgStab / tfqmr amplify last-bit differences of the dot products by ~1e6, so they
+ * hold 1e-10 against an oracle that sums in the library's own fixed reduction tree (one rank) and 1e-7,
+ * with a stop that may move by one iteration, between different rank counts (the all-reduce changes the
+ * summation order, as it does between MPI rank counts in the reference: separate golds per np,
+ * reg_tests/CTestList.cmake:133-135). */
 enum { NALU_GPU_METHOD_CG = 0, NALU_GPU_METHOD_GMRES = 1, NALU_GPU_METHOD_BICGSTAB = 2, NALU_GPU_METHOD_TFQMR = 3 };
 enum { NALU_GPU_PRECOND_NONE = 0, NALU_GPU_PRECOND_JACOBI = 1, NALU_GPU_PRECOND_SGS = 2,
        NALU_GPU_PRECOND_CHEBYSHEV = 3,

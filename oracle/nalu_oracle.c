@@ -1071,16 +1071,77 @@ void orc_spmv(const orc_linsys *ls, const double *x, double *y)
   }
 }
 
+/* Dot products.  Tpetra's dot / norm2 (src/LinearSolver.C:172, src/TpetraLinearSystem.C:1756; Kokkos
+ * parallel_reduce underneath) fix no summation order; the default here is the plain sequential sum.
+ * orc_set_dot_tree(1) selects another deterministic order: the fixed reduction tree of the device
+ * library's dot products (nalu_amd/csrc/solve.hip: grid-stride per-thread sums over ceil(n / 1024)
+ * workgroups of 256 threads, a shuffle tree over the 64 lanes of a wave, the four wave sums in order, then
+ * one 1024-thread pass over the workgroup partials with the same lane tree and a tree over its 16 wave
+ * sums).  The tests of BiCGStab and TFQMR use it: their short recurrences amplify the last-bit
+ * differences between two summation orders by ~1e6 over a solve, so the two sides have to agree on ONE
+ * order before their residual histories can be compared to 1e-10 (cg and gmres hold 1e-10 with either). */
+static int g_dot_tree = 0;
+void orc_set_dot_tree(int on) { g_dot_tree = on; }
+
+#define ORC_TREE_MAX_BLOCKS 16384
+static double lane_tree(double *v, int width)
+{ /* v[l] += v[l + o] for o = width / 2 ... 1: __shfl_down trees (lanes beyond the width hold zero) */
+  for (int o = width / 2; o > 0; o >>= 1)
+    for (int l = 0; l < o; ++l) v[l] += v[l + o];
+  return v[0];
+}
+
+static double dot_tree(const double *a, const double *b, int64_t n)
+{
+  int64_t vb = (n + 1023) / 1024;
+  if (vb < 1) vb = 1;
+  if (vb > ORC_TREE_MAX_BLOCKS) vb = ORC_TREE_MAX_BLOCKS;
+  const int64_t T = vb * 256;
+  double *part = (double *)malloc(sizeof(double) * (size_t)vb);
+  for (int64_t B = 0; B < vb; ++B) {
+    double s4[4];
+    for (int w = 0; w < 4; ++w) {
+      double v[64];
+      for (int l = 0; l < 64; ++l) {
+        double acc = 0.0;
+        for (int64_t i = B * 256 + w * 64 + l; i < n; i += T) acc += a[i] * b[i];
+        v[l] = acc;
+      }
+      s4[w] = lane_tree(v, 64);
+    }
+    part[B] = ((s4[0] + s4[1]) + s4[2]) + s4[3];
+  }
+  double s16[64];
+  for (int w = 0; w < 64; ++w) s16[w] = 0.0;
+  for (int w = 0; w < 16; ++w) {
+    double v[64];
+    for (int l = 0; l < 64; ++l) {
+      const int64_t tid = w * 64 + l;
+      double acc = 0.0;
+      for (int64_t i0 = tid; i0 < vb; i0 += 8192)
+        for (int u = 0; u < 8; ++u) acc += (i0 + u * 1024 < vb) ? part[i0 + u * 1024] : 0.0;
+      v[l] = acc;
+    }
+    s16[w] = lane_tree(v, 64);
+  }
+  free(part);
+  return lane_tree(s16, 16);
+}
+
 double orc_norm2(const double *v, int64_t n)
 {
+  if (g_dot_tree) return sqrt(dot_tree(v, v, n));
   double s = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : s)
   for (int64_t i = 0; i < n; ++i) s += v[i] * v[i];
   return sqrt(s);
 }
 
-static double dot(const double *a, const double *b, int64_t n)
+double orc_dot(const double *a, const double *b, int64_t n);
+static double dot(const double *a, const double *b, int64_t n) { return orc_dot(a, b, n); }
+double orc_dot(const double *a, const double *b, int64_t n)
 {
+  if (g_dot_tree) return dot_tree(a, b, n);
   double s = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : s)
   for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
@@ -1110,8 +1171,6 @@ double orc_cheb_start_value(int64_t gid)
   h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
   return (double)h / 4294967296.0 * 2.0 - 1.0;
 }
-
-static double dot(const double *a, const double *b, int64_t n);
 
 static double cheb_power_method(const orc_linsys *ls, const double *dinv)
 {

@@ -195,6 +195,10 @@ typedef struct {
 int orc_solve(orc_linsys *ls, const orc_solver_config *cfg, double *finalResidNrm,
               double *history, int history_cap, int *history_len);
 double orc_norm2(const double *v, int64_t n);
+/* summation order of the solver's dot products and norms: 0 (default) sequential, 1 the fixed reduction
+ * tree the device library uses (see nalu_oracle.c) -- both are restatements of "a deterministic dot product" */
+void orc_set_dot_tree(int on);
+double orc_dot(const double *a, const double *b, int64_t n);
 /* greedy colouring in row order used by precond 4; color has nrows entries; returns #colours */
 int orc_greedy_colors(const orc_linsys *ls, int *color);
 

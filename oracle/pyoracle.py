@@ -121,6 +121,10 @@ def _bind(lib):
     lib.orc_solve.argtypes = [C.POINTER(_LinSys), C.POINTER(SolverConfig), C.POINTER(C.c_double),
                               _dp, C.c_int, C.POINTER(C.c_int)]
     lib.orc_solve.restype = C.c_int
+    lib.orc_set_dot_tree.argtypes = [C.c_int]
+    lib.orc_set_dot_tree.restype = None
+    lib.orc_dot.argtypes = [_dp, _dp, C.c_int64]
+    lib.orc_dot.restype = C.c_double
     lib.orc_norm2.argtypes = [_dp, C.c_int64]
     lib.orc_greedy_colors.argtypes = [C.POINTER(_LinSys), _ip]
     lib.orc_greedy_colors.restype = C.c_int
@@ -289,14 +293,31 @@ class LinSys:
         self.L.orc_spmv(self.p, f64(x), y)
         return y
 
-    def solve(self, method="cg", precond="jacobi", tolerance=1e-4, max_iterations=50, kspace=50):
+    def solve(self, method="cg", precond="jacobi", tolerance=1e-4, max_iterations=50, kspace=50, dot_tree=False):
+        """dot_tree: the dot products and norms summed in the device library's fixed reduction tree instead of
+        sequentially (orc_set_dot_tree; what BiCGStab / TFQMR need for a 1e-10 comparison)"""
         cfg = SolverConfig(METHODS[method], PRECONDS[precond], tolerance, max_iterations, kspace)
         hist = np.zeros(max_iterations + 2)
         hl = C.c_int(0)
         fr = C.c_double(0.0)
-        iters = self.L.orc_solve(self.p, C.byref(cfg), C.byref(fr), hist, len(hist), C.byref(hl))
+        self.L.orc_set_dot_tree(1 if dot_tree else 0)
+        try:
+            iters = self.L.orc_solve(self.p, C.byref(cfg), C.byref(fr), hist, len(hist), C.byref(hl))
+        finally:
+            self.L.orc_set_dot_tree(0)
         return dict(iters=iters, final_resid=fr.value, history=hist[:hl.value].copy(),
                     x=self.solution())
+
+
+def dot(a, b, tree=False):
+    """a . b summed sequentially, or (tree) in the device library's fixed reduction tree"""
+    a, b = f64(a), f64(b)
+    L = lib()
+    L.orc_set_dot_tree(1 if tree else 0)
+    try:
+        return L.orc_dot(a, b, a.size)
+    finally:
+        L.orc_set_dot_tree(0)
 
 
 def scalar_opts(alpha=0.0, alpha_upw=1.0, upw_factor=1.0, limiter=False, peclet="classic",
