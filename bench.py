@@ -54,6 +54,24 @@ def traffic_of(pmc, names):
     return None if (not got or any(v is None for v in got)) else float(sum(got))
 
 
+def block_parts(nranks):
+    """(px, py, pz) of the brick partition of `--partition block`: the factors of nranks spread over z, y, x
+    (2 -> 1x1x2, 4 -> 1x2x2, 8 -> 2x2x2, 16 -> 2x2x4)"""
+    parts = [1, 1, 1]
+    d, n, f = 2, nranks, 2
+    while n > 1:
+        while n % f:
+            f += 1
+        parts[d] *= f
+        n //= f
+        d = (d - 1) % 3
+    return tuple(parts)
+
+
+def partition_text(parts, world):
+    return f"z-slabs x{world}" if parts is None else "bricks %dx%dx%d" % tuple(parts)
+
+
 def box_counts(nx, ny, nz):
     N = nx * ny * nz
     E = (nx - 1) * ny * nz + nx * (ny - 1) * nz + nx * ny * (nz - 1)
@@ -72,17 +90,24 @@ def workload_dims(n, nranks, scaling):
 class RankSystem:
     """One rank's share of a box: mesh slab, synthetic fields, linear system, comm."""
 
-    def __init__(self, dims, rank, nranks, device, world=None, backend="nccl", edge_order=None):
+    def __init__(self, dims, rank, nranks, device, world=None, backend="nccl", edge_order=None, parts=None):
+        """parts: None = z-slabs; (px, py, pz) = bricks (`--partition block`: 2 x 2 x 2 on eight GPUs, one
+        neighbour per xGMI link, faces a quarter of a slab's planes)"""
         import torch
         import nalu_amd
         from nalu_amd import synth
         nx, ny, nz = dims
         self.dims = dims
+        self.parts = parts
         self.edge_order = edge_order or os.environ.get("NALU_EDGE_ORDER", "slot")
         L = float(max(nx, ny, nz) - 1)
-        self.S = S = nalu_amd.BoxSlab(nx, ny, nz, rank, nranks,
-                                      lengths=((nx - 1) / L, (ny - 1) / L, (nz - 1) / L),
-                                      edge_order=self.edge_order)
+        lengths = ((nx - 1) / L, (ny - 1) / L, (nz - 1) / L)
+        if parts is not None and nranks > 1:
+            from nalu_amd.box import BoxBlock
+            assert parts[0] * parts[1] * parts[2] == nranks, (parts, nranks)
+            self.S = S = BoxBlock(nx, ny, nz, rank, parts, lengths=lengths, edge_order=self.edge_order)
+        else:
+            self.S = S = nalu_amd.BoxSlab(nx, ny, nz, rank, nranks, lengths=lengths, edge_order=self.edge_order)
         vol, area = S.uniform_geometry()
         xyz = S.coords()
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=device)
@@ -100,7 +125,7 @@ class RankSystem:
         self.comm = None
         self.comm_kind = "none"
         if nranks > 1:
-            g.set_halo_plan(S.neighbors, S.send_offsets, S.send_lids, S.recv_offsets)
+            g.set_halo_plan(S.neighbors, S.send_offsets, S.send_lids, S.recv_offsets, getattr(S, "recv_lids", None))
             if backend == "nccl" and world is not None:
                 self.comm = world.attach(g)  # libnalu_gpu_rccl.so: native RCCL callbacks
                 self.comm_kind = "rccl-native"
@@ -246,6 +271,10 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): n^3 nodes per GPU; strong: one n^3 box split over the GPUs")
     ap.add_argument("--no-strong-record", action="store_true", help="N > 1: skip the strong-scaling sub-record")
+    ap.add_argument("--partition", default="slab", choices=["slab", "block"],
+                    help="N > 1: z-slabs (default) or bricks (block_parts(N): 2 x 2 x 2 on eight GPUs) for the "
+                         "n^3 box of --scaling strong and of the strong sub-record; the weak-scaling box is "
+                         "always cut in z-slabs (it grows in z with N)")
     ap.add_argument("--no-ttt", action="store_true", help="skip the time-to-tolerance record (N = 1)")
     ap.add_argument("--check-every", type=int, default=0,
                     help="iterations between host polls of the device convergence flag (0 = library default 10; "
@@ -305,7 +334,8 @@ def main():
     import nalu_amd
     n = a.n
     dims = workload_dims(n, world, a.scaling)
-    R = RankSystem(dims, rank, world, device, rworld, backend)
+    parts = block_parts(world) if (a.partition == "block" and world > 1) else None
+    R = RankSystem(dims, rank, world, device, rworld, backend, parts=parts if a.scaling == "strong" else None)
     S, F, g = R.S, R.F, R.g
     cfg = nalu_amd.LinearSolverConfig(method="cg", preconditioner="jacobi", tolerance=1e-5,
                                       max_iterations=50, kspace=50, check_every=a.check_every)
@@ -435,14 +465,15 @@ def main():
     # strong-scaling sub-record: the 256^3 box of BASELINE config 3 split over the N GPUs
     strong = None
     if world > 1 and a.scaling == "weak" and not a.no_strong_record:
-        Rs = RankSystem((n, n, n), rank, world, device, rworld, backend)
+        Rs = RankSystem((n, n, n), rank, world, device, rworld, backend, parts=parts)
         eqs = Rs.continuity_eqsys(cfg, a.mode)
         dts = max_over_ranks(timed_steps(eqs, Rs.g, a.steps, a.warmup, barrier))
         s_solve_ms, _ = Rs.g.timer("solve")
         s_spmv_ms, s_spmv_cnt = Rs.g.timer("spmv")
         Rs.g.set_profiling(False)
         Ns, Es, _ = box_counts(n, n, n)
-        strong = {"workload": f"Hex8 box {n}^3 nodes split over {world} GPUs (z-slabs): the same step",
+        strong = {"workload": f"Hex8 box {n}^3 nodes split over {world} GPUs ({partition_text(parts, world)}): the same step",
+                  "partition": partition_text(parts, world), "neighbours": int(len(Rs.S.neighbors)),
                   "value": Es * a.steps / dts, "unit": "edges/s", "ms_per_step": dts / a.steps * 1e3,
                   "nodes": Ns, "edges": Es, "solver_iterations": Rs.g.linearSolveIterations,
                   "solve_ms_per_iteration": s_solve_ms / a.steps / max(Rs.g.linearSolveIterations, 1),
@@ -489,7 +520,7 @@ def main():
             "config": {"workload": wl + step_txt,
                        "nodes": Ng, "edges": Eg, "nodes_per_gpu": Nl, "scatter": a.mode, "solver_iterations": iters,
                        "graph_setup_s": round(R.graph_setup_s, 3),
-                       "parallelism": f"z-slabs x{world}", "comm": R.comm_kind,
+                       "parallelism": partition_text(R.parts, world), "comm": R.comm_kind,
                        "edge_order": R.edge_order, "assembly_variant": layout["assembly_variant"],
                        "xcd_run": layout["xcd_run"],
                        "rows_computed_tags": layout["rows_computed_tags"],

@@ -187,22 +187,32 @@ class BoxBlock:
         self.i = (g0 % nxn).astype(np.int32)
         self.j = ((g0 // nxn) % nyn).astype(np.int32)
         self.k = (g0 // (nxn * nyn)).astype(np.int32)
-        lid_of = {int(g): n for n, g in enumerate(self.gids)}
+        # gid -> local id (all in numpy: a rank of a 512^3 box holds 17 M nodes)
+        order = np.argsort(self.gids, kind="stable")
+        sg = self.gids[order]
+
+        def lid_of(g):
+            pos = np.searchsorted(sg, g)
+            assert np.array_equal(sg[pos], g), "node is not held by this rank"
+            return order[pos]
         # local edges: every lattice edge with an owned end, oriented low gid -> high gid, sorted (L, R)
-        ed, en = [], []
         step = (1, nxn, nxn * nyn)
         lim = (nxn, nyn, nzn)
         idx = (self.i, self.j, self.k)
-        for n in range(self.n_owned):
-            g = int(self.gids[n])
-            for d in range(3):
-                if idx[d][n] + 1 < lim[d]:
-                    en.append((n, lid_of[g + step[d]])); ed.append(d)
-                if idx[d][n] > 0:
-                    m = lid_of[g - step[d]]
-                    if m >= self.n_owned:  # (owned-owned edges are listed from their lower end)
-                        en.append((m, n)); ed.append(d)
-        en, ed = np.array(en, np.int64).reshape(-1, 2), np.array(ed, np.int8)
+        no = self.n_owned
+        og = self.gids[:no]
+        on = np.arange(no, dtype=np.int64)
+        ens, eds = [], []
+        for d in range(3):
+            up = idx[d][:no] + 1 < lim[d]
+            ens.append(np.stack([on[up], lid_of(og[up] + step[d])], axis=1))
+            eds.append(np.full(int(up.sum()), d, np.int8))
+            dn = idx[d][:no] > 0
+            m = lid_of(og[dn] - step[d])
+            sel = m >= no  # (owned-owned edges are listed from their lower end)
+            ens.append(np.stack([m[sel], on[dn][sel]], axis=1))
+            eds.append(np.full(int(sel.sum()), d, np.int8))
+        en, ed = np.concatenate(ens).astype(np.int64).reshape(-1, 2), np.concatenate(eds)
         gl, gr = self.gids[en[:, 0]], self.gids[en[:, 1]]
         o = np.lexsort((gr, gl))
         if edge_order == "slot":
@@ -211,25 +221,25 @@ class BoxBlock:
         self.edge_dir = ed[o]
         self.n_edges = len(ed)
         # halo plan: what each neighbour holds of mine, in ITS local order; what I hold of its
-        nbrs = sorted(set(int(r) for r in self.owners[self.n_owned:]) |
+        nbrs = sorted(set(int(r) for r in np.unique(self.owners[self.n_owned:])) |
                       set(q for q in self._adjacent_ranks() if self._needs_from(q, rank)))
         so, sl, ro, rl = [0], [], [0], []
         for q in nbrs:
             theirs = self._rank_nodes(q)
             tg = np.concatenate([theirs["shared"][0], theirs["ghost"][0]])
             to = np.concatenate([theirs["shared"][1], theirs["ghost"][1]])
-            send = [lid_of[int(g)] for g in tg[to == rank]]
-            sl += send
+            send = lid_of(tg[to == rank])
+            sl.append(send)
             so.append(so[-1] + len(send))
             mine = np.nonzero(self.owners[self.n_owned:] == q)[0] + self.n_owned
-            rl += [int(c) for c in mine]
+            rl.append(mine)
             ro.append(ro[-1] + len(mine))
         keep = [n for n in range(len(nbrs)) if so[n + 1] > so[n] or ro[n + 1] > ro[n]]
         self.neighbors = np.array([nbrs[n] for n in keep], np.int32)
         self.send_offsets = np.array([0] + [so[n + 1] for n in keep], np.int32)
         self.recv_offsets = np.array([0] + [ro[n + 1] for n in keep], np.int32)
-        self.send_lids = np.array(sl, np.int32)
-        self.recv_lids = np.array(rl, np.int32)
+        self.send_lids = (np.concatenate(sl) if sl else np.zeros(0)).astype(np.int32)
+        self.recv_lids = (np.concatenate(rl) if rl else np.zeros(0)).astype(np.int32)
 
     # ---- partition geometry
     def _coords_of(self, rank):
@@ -255,43 +265,51 @@ class BoxBlock:
         t = self._rank_nodes(q)
         return bool((np.concatenate([t["shared"][1], t["ghost"][1]]) == owner).any())
 
-    def _owner_of(self, i, j, k):
-        """lowest rank whose element brick holds node (i, j, k)"""
-        c = []
-        for d, v in enumerate((i, j, k)):
+    def _dim_owner(self, d):
+        """per node index of dimension d: the lowest part whose element range holds it"""
+        cache = self.__dict__.setdefault("_dim_owner_cache", {})
+        if d not in cache:
             rng = split_elems(self.dims[d] - 1, self.parts[d])
-            c.append(min(p for p, (e0, e1) in enumerate(rng) if e0 <= v <= e1))
+            ow = np.empty(self.dims[d], np.int64)
+            for p in reversed(range(self.parts[d])):  # (lower parts overwrite: the lowest holder owns)
+                ow[rng[p][0]:rng[p][1] + 1] = p
+            cache[d] = ow
+        return cache[d]
+
+    def _owner_of(self, i, j, k):
+        """lowest rank whose element brick holds node (i, j, k) (arrays or scalars)"""
+        c = [self._dim_owner(d)[v] for d, v in enumerate((i, j, k))]
         return c[0] + self.parts[0] * (c[1] + self.parts[1] * c[2])
 
     def _rank_nodes(self, rank):
+        """gids and owners of a rank's owned nodes (sorted by gid), shared-not-owned nodes (sorted by gid) and
+        ghosts (lattice neighbours of owned nodes outside the brick, sorted by (owner, gid))"""
         cache = self.__dict__.setdefault("_cache", {})
         if rank in cache:
             return cache[rank]
         nxn, nyn, nzn = self.dims
         er = self._elem_ranges(rank)
-        gid = lambda i, j, k: 1 + i + nxn * (j + nyn * k)
-        owned, shared = [], []
-        for k in range(er[2][0], er[2][1] + 1):
-            for j in range(er[1][0], er[1][1] + 1):
-                for i in range(er[0][0], er[0][1] + 1):
-                    o = self._owner_of(i, j, k)
-                    (owned if o == rank else shared).append((gid(i, j, k), o))
-        ownset = {g for g, _ in owned}
-        held = ownset | {g for g, _ in shared}
-        ghost = {}
-        step = (1, nxn, nxn * nyn)
-        for g, _ in owned:  # lattice neighbours of owned nodes outside the brick
-            i, j, k = (g - 1) % nxn, ((g - 1) // nxn) % nyn, (g - 1) // (nxn * nyn)
-            for d, (v, lim) in enumerate(((i, nxn), (j, nyn), (k, nzn))):
-                for s in (-1, 1):
-                    if 0 <= v + s < lim and g + s * step[d] not in held:
-                        h = g + s * step[d]
-                        hi, hj, hk = (h - 1) % nxn, ((h - 1) // nxn) % nyn, (h - 1) // (nxn * nyn)
-                        ghost[h] = self._owner_of(hi, hj, hk)
-        srt = lambda lst, key: (np.array([g for g, _ in sorted(lst, key=key)], np.int64),
-                                np.array([o for _, o in sorted(lst, key=key)], np.int64))
-        out = dict(owned=srt(owned, lambda t: t[0]), shared=srt(shared, lambda t: t[0]),
-                   ghost=srt(list(ghost.items()), lambda t: (t[1], t[0])))
+        ax = [np.arange(er[d][0], er[d][1] + 1, dtype=np.int64) for d in range(3)]
+        k, j, i = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")  # (i fastest: ascending gid)
+        i, j, k = i.reshape(-1), j.reshape(-1), k.reshape(-1)
+        gid = 1 + i + nxn * (j + nyn * k)
+        own = self._owner_of(i, j, k)
+        mine = own == rank
+        owned = (gid[mine], own[mine])
+        shared = (gid[~mine], own[~mine])
+        # ghosts: a neighbour that differs in one coordinate leaves the brick iff that coordinate leaves its range
+        oi = (i[mine], j[mine], k[mine])
+        gh = []
+        for d, lim in enumerate((nxn, nyn, nzn)):
+            for s in (-1, 1):
+                v = oi[d] + s
+                out = (v >= 0) & (v < lim) & ((v < er[d][0]) | (v > er[d][1]))
+                c = [oi[0][out], oi[1][out], oi[2][out]]
+                c[d] = v[out]
+                gh.append(np.stack([1 + c[0] + nxn * (c[1] + nyn * c[2]), self._owner_of(*c)], axis=1))
+        gh = np.unique(np.concatenate(gh), axis=0) if gh else np.zeros((0, 2), np.int64)
+        o = np.lexsort((gh[:, 0], gh[:, 1]))
+        out = dict(owned=owned, shared=shared, ghost=(gh[o, 0], gh[o, 1]))
         cache[rank] = out
         return out
 

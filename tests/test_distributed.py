@@ -157,3 +157,25 @@ def test_bench_multirank_path_rehearsal():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert d["config"]["nodes"] == 48 * 48 * 96 and d["config"]["solver_iterations"] == 50
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_block_partition_rehearsal():
+    """bench.py --gpus 4 --partition block: the strong sub-record on 1 x 2 x 2 bricks (indexed halo plan, three
+    neighbours per rank) next to the weak-scaling slabs, four gloo ranks on the one GPU."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", NALU_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + (os.getpid() + 11) % 500),
+           os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--box", "32",
+           "--partition", "block"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["parallelism"] == "z-slabs x4"
+    st = d["strong"]
+    assert st["partition"] == "bricks 1x2x2" and st["neighbours"] == 3 and st["nodes"] == 32 ** 3
+    assert st["solver_iterations"] == 50 and st["value"] > 0
