@@ -457,3 +457,31 @@ def test_baseline_configs_3_and_4_full_size_against_the_oracle(G, torch, oracle)
     ref = ls.solve("gmres", "jacobi", dot_tree=True, **kw)
     assert ref["iters"] == 15
     _check_solve(g, ref, ls, kw, xout)
+
+
+@pytest.mark.timeout(900)
+def test_baseline_config_5_per_gpu_slab_against_the_oracle(G, torch, oracle):
+    """BASELINE config 5's per-GPU share -- the 512 x 512 x 64-node slab of the weak-scaling run (16.8 M nodes,
+    two slices per x-line) -- as a box of its own against the ORACLE: continuity assembly + pinned node bit for
+    bit, 50 Jacobi-CG iterations to 1e-10.  (The full 512^3 box: eight ranks against one rank on the GPU,
+    tests/test_distributed.py; the oracle would need ~8 x the memory and time of this test for it.)"""
+    c = BenchCase(G, oracle, (512, 512, 64))
+    d = c.dev(torch)
+    S = c.S
+    kw = dict(tolerance=1e-5, max_iterations=50)
+    xout = torch.zeros(S.n_local, dtype=torch.float64, device="cuda:0")
+    g = _bench_step(G, torch, c, d, G.LinearSolverConfig(method="cg", preconditioner="jacobi", **kw), xout)
+    li = g.layout_info()
+    assert li["assembly_variant"] == 6 and li["march_slices"] > 0.9 * li["n_slices"], li
+    ls = oracle.LinSys(1, S.n_owned, fast="omp")
+    ls.add_connections(c.en_sorted)
+    ls.finalize()
+    ls.prepare_edge_buckets(c.en_sorted)
+    ls.zero()
+    ls.assemble_continuity(c.en_sorted, c.area_sorted, c.xyz, c.dpdx, c.vel, c.p, c.rho, c.dt, 1.0, 1.0, 1.0)
+    ls.reset_rows([0])
+    ls.sum_into([0], [0.0 - c.p[0]], [1.0])
+    _equal_system(g, ls)
+    ref = ls.solve("cg", "jacobi", dot_tree=True, **kw)
+    assert ref["iters"] == 50
+    _check_solve(g, ref, ls, kw, xout)
