@@ -455,18 +455,17 @@ __global__ __launch_bounds__(SELL_C, ORDERED ? Op::kOrderedWaves : 1) void k_ass
 template <class Op> struct BurstCfg { static constexpr int NB = 6, WAVES = 2; };
 template <> struct BurstCfg<ScalOp> { static constexpr int NB = 3, WAVES = 2; };
 
+// (the body: one 256-thread workgroup assembles slice `slice`; lds: NF * SELL_C doubles.  Also called by the tail
+// workgroups of k_assemble_rows_lagpf, which take the slices outside the runs in the same launch)
 template <class Op, bool SET>
-__global__ __launch_bounds__(SELL_C, BurstCfg<Op>::WAVES) void k_assemble_rows_burst(SellView A, typename Op::Params P,
-                                                                                 double *__restrict__ rhs, int listBase)
+__device__ __forceinline__ void burst_slice(const SellView &A, const typename Op::Params &P, double *__restrict__ rhs,
+                                            int slice, double *lds)
 {
   using Node = typename Op::Node;
   using Edge = typename Op::Edge;
   constexpr int NF = sizeof(Node) / sizeof(double);
   constexpr int NB = BurstCfg<Op>::NB;
   constexpr int NE = BURST_NE;  // edges per row taken by the bursts; further ones go through the tail loop
-  __shared__ double lds[NF * SELL_C];
-  // (listBase >= 0: the single-slice runs A.march[listBase ...] that the marching kernel leaves)
-  const int slice = listBase < 0 ? sched_slice(A, blockIdx.x) : A.march[listBase + blockIdx.x].start;
   const int r = threadIdx.x;
   const int sBase = slice * SELL_C;
   const int row = sBase + r;
@@ -614,6 +613,16 @@ __global__ __launch_bounds__(SELL_C, BurstCfg<Op>::WAVES) void k_assemble_rows_b
   }
   if (SET) rhs[row] = b;
   else rhs[row] += b;
+}
+
+template <class Op, bool SET>
+__global__ __launch_bounds__(SELL_C, BurstCfg<Op>::WAVES) void k_assemble_rows_burst(SellView A, typename Op::Params P,
+                                                                                 double *__restrict__ rhs, int listBase)
+{
+  __shared__ double lds[sizeof(typename Op::Node) / sizeof(double) * SELL_C];
+  // (listBase >= 0: the single-slice runs A.march[listBase ...] that the marching kernel leaves)
+  const int slice = listBase < 0 ? sched_slice(A, blockIdx.x) : A.march[listBase + blockIdx.x].start;
+  burst_slice<Op, SET>(A, P, rhs, slice, lds);
 }
 
 // Marching burst row gather (NG_ASM_MARCH=1): a workgroup walks a run of slices whose rows continue
@@ -1093,7 +1102,7 @@ template <class Op, bool SET, int GY>
 __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_assemble_rows_lagpf(SellView A, typename Op::Params P,
                                                                   double *__restrict__ rhs,
                                                                   const int *__restrict__ list, int nItems,
-                                                                  long long nEdges)
+                                                                  long long nEdges, int burstBase)
 {
   using Node = typename Op::Node;
   using Edge = typename Op::Edge;
@@ -1105,6 +1114,14 @@ __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_
   constexpr int NW = GY > 1 ? GY : SELL_C / 64;  // waves per workgroup
   constexpr int QS = SELL_C / 64;                // quarters per slice: a group is QS consecutive items
   __shared__ double ldsAll[NW * L::kDoubles];
+  // The workgroups behind the last item take the slices outside the runs (the mesh's boundary planes and lines) in
+  // their burst form, one slice each: in the same launch they fill the CUs that the last runs leave one by one,
+  // instead of waiting for the whole grid to drain (a launch of their own: 26 of 875 us at 256^3).
+  if (GY <= 4 && (int)blockIdx.x >= nItems) {
+    static_assert(GY > 4 || NW * L::kDoubles >= NF * SELL_C, "the burst form stages a slice's nodal data in LDS");
+    burst_slice<Op, SET>(A, P, rhs, A.march[burstBase + ((int)blockIdx.x - nItems)].start, ldsAll);
+    return;
+  }
   const int r = threadIdx.x, lane = r & 63;
   const int wv = __builtin_amdgcn_readfirstlane(r >> 6);
   const int item = xcd_run(blockIdx.x, nItems, GY > 1 ? A.marchXcdRun * (SELL_C / 64) : A.marchXcdRun);
@@ -1629,19 +1646,22 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
         const bool pf = lag_prefetch(h);
         const int nG = grouped ? h->nMarchGroups : 0, nS = grouped ? h->nMarchSingles : nPat;
         const int *singles = grouped ? h->dMarchSingles : nullptr;
+        bool restDone = false;  // the slices outside the runs were taken by the tail workgroups of a launch
         if (grouped && pf) {  // (every pattern run in one launch: incomplete groups have idle waves)
           const int nP = h->nMarchGroupsP, nI = (SELL_C / 64) * nP;  // items: the four quarters of every group
           if (nI == 0) {
           } else if (h->marchGY == 8) {
-            if (set) k_assemble_rows_lagpf<Op, true, 8><<<nI, 512, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges);
-            else k_assemble_rows_lagpf<Op, false, 8><<<nI, 512, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges);
+            if (set) k_assemble_rows_lagpf<Op, true, 8><<<nI, 512, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges, 0);
+            else k_assemble_rows_lagpf<Op, false, 8><<<nI, 512, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges, 0);
           } else {
-            if (set) k_assemble_rows_lagpf<Op, true, 4><<<nI, 256, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges);
-            else k_assemble_rows_lagpf<Op, false, 4><<<nI, 256, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges);
+            const int nT = env_not_zero("NG_ASM_LAG_TAIL") ? nRest : 0;  // (NG_ASM_LAG_TAIL=0: the burst kernel in a launch of its own)
+            if (set) k_assemble_rows_lagpf<Op, true, 4><<<nI + nT, 256, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges, nPat);
+            else k_assemble_rows_lagpf<Op, false, 4><<<nI + nT, 256, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges, nPat);
+            restDone = nT == nRest;
           }
           if (const int n1 = h->nMarchSinglesP) {  // (lines without a neighbour to group with)
-            if (set) k_assemble_rows_lagpf<Op, true, 1><<<n1, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchSinglesP, n1, h->nEdges);
-            else k_assemble_rows_lagpf<Op, false, 1><<<n1, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchSinglesP, n1, h->nEdges);
+            if (set) k_assemble_rows_lagpf<Op, true, 1><<<n1, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchSinglesP, n1, h->nEdges, 0);
+            else k_assemble_rows_lagpf<Op, false, 1><<<n1, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchSinglesP, n1, h->nEdges, 0);
           }
         } else if (nG > 0) {
           if (set) k_assemble_rows_lag<Op, true, 4><<<4 * nG, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroups, 4 * nG);
@@ -1649,19 +1669,25 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
         }
         if (grouped && pf) {
         } else if (nS > 0 && pf) {
-          if (set) k_assemble_rows_lagpf<Op, true, 1><<<nS, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, singles, nS, h->nEdges);
-          else k_assemble_rows_lagpf<Op, false, 1><<<nS, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, singles, nS, h->nEdges);
+          if (set) k_assemble_rows_lagpf<Op, true, 1><<<nS, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, singles, nS, h->nEdges, 0);
+          else k_assemble_rows_lagpf<Op, false, 1><<<nS, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, singles, nS, h->nEdges, 0);
         } else if (nS > 0) {
           if (set) k_assemble_rows_lag<Op, true, 1><<<nS, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, singles, nS);
           else k_assemble_rows_lag<Op, false, 1><<<nS, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, singles, nS);
         }
-      } else if (nPat > 0) {
-        if (set) k_assemble_rows_march<Op, true><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
-        else k_assemble_rows_march<Op, false><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
-      }
-      if (nRest > 0) {
-        if (set) k_assemble_rows_burst<Op, true><<<nRest, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, nPat);
-        else k_assemble_rows_burst<Op, false><<<nRest, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, nPat);
+        if (nRest > 0 && !restDone) {
+          if (set) k_assemble_rows_burst<Op, true><<<nRest, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, nPat);
+          else k_assemble_rows_burst<Op, false><<<nRest, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, nPat);
+        }
+      } else {
+        if (nPat > 0) {
+          if (set) k_assemble_rows_march<Op, true><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+          else k_assemble_rows_march<Op, false><<<nPat, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs);
+        }
+        if (nRest > 0) {
+          if (set) k_assemble_rows_burst<Op, true><<<nRest, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, nPat);
+          else k_assemble_rows_burst<Op, false><<<nRest, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, nPat);
+        }
       }
     } else if (h->asmVariant == 3 && h->dBurst && !h->dEdgeOwned) {
       if (set) k_assemble_rows_burst<Op, true><<<h->nSlices, SELL_C, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, -1);

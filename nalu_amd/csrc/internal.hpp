@@ -72,7 +72,7 @@ struct MarchSeg {
   int pad3[8];
 };
 static_assert(sizeof(MarchSeg) == 192, "march run layout");
-constexpr int MARCH_MAX_LEN = 16;
+constexpr int MARCH_MAX_LEN = 32;  // (16 until the second half of round 3: a run's first step pays an exposed round trip; 64 measures the same, 128 worse)
 // the slot pattern the marching kernel is specialised for (a slice qualifies when, for every row,
 // the neighbours of the slots in MARCH_NEAR are rows of the slice and those of the other slots are
 // not; an irregular row's edges are placed in the slots of the regular rows' offsets they match):

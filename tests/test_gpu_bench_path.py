@@ -136,8 +136,8 @@ SLOT_CASES = [
     ((256, 5, 4), 0.125, 0.9),    # ... on a distorted mesh (non-orthogonal correction active)
     ((512, 3, 3), 0.125, 0.9),    # two slices per x-line (the 512^3 geometry)
     ((300, 4, 3), 0.0, 0.0),      # x-lines straddle slices: mixed flagged / computed rows
-    ((256, 6, 20), 0.125, 0.9),   # long z-runs for the marching kernel (carried edge over 16 steps)
-    ((512, 6, 20), 0.125, 0.9),   # ... with two slices per x-line: the node across the slice boundary is staged too
+    ((256, 6, 40), 0.125, 0.9),   # long z-runs for the marching kernels: 38 interior planes = a run of 32 slices + one of 6
+    ((512, 6, 40), 0.125, 0.9),   # ... with two slices per x-line: the node across the slice boundary is staged too
     ((256, 13, 7), 0.125, 0.9),   # 11 interior lines: groups of 4 + 4 + 3 (or 8 + 3) adjacent lines
     ((256, 7, 5), 0.125, 0.9),    # 5 interior lines: a group of four and ONE line left over (the kernel's single-run form)
     ((256, 3, 6), 0.125, 0.9),    # 1 interior line per plane: no groups at all
@@ -182,10 +182,10 @@ def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, pert
                                       "lag_nopf": lag if marching else 0, "lag_groups": lag if marching else 0,
                                       "lag_pf": lagpf if marching else 0,
                                       "lag_pf_groups8": lagpf if marching else 0}[variant], li
-    if dims == (256, 6, 20):  # 4 interior lines x 18 interior planes: runs of 16 + 2 slices
-        assert marching and li["march_longest"] == 16 and li["march_slices"] == 72 and li["march_runs"] == 8, li
-    if dims == (512, 6, 20):  # ... two slices per line
-        assert marching and li["march_longest"] == 16 and li["march_slices"] == 144 and li["march_runs"] == 16, li
+    if dims == (256, 6, 40):  # 4 interior lines x 38 interior planes: runs of 32 + 6 slices
+        assert marching and li["march_longest"] == 32 and li["march_slices"] == 152 and li["march_runs"] == 8, li
+    if dims == (512, 6, 40):  # ... two slices per line
+        assert marching and li["march_longest"] == 32 and li["march_slices"] == 304 and li["march_runs"] == 16, li
     assert li["rows_computed_tags"] >= min_computed * n, li
     assert li["rows_computed_columns"] >= min_computed * n, li
     if min_computed > 0:  # and the boundary rows of the x-lines are the flagged exceptions
