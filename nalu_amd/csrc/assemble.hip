@@ -35,6 +35,8 @@ struct ContOp {
     a.rho = P.f.density[n];
     return a;
   }
+  // (a node assembled from its raw fields -- the prefetching kernel's LDS copies -- is finished like a loaded one)
+  __device__ static __forceinline__ void finish(Node &) {}
   // the f-th nodal / c-th edge field in the order of Node / Edge (the prefetching kernel addresses them by index)
   __device__ static __forceinline__ const double *node_field(const Params &P, int f)
   {
@@ -119,9 +121,12 @@ struct ScalParams {
 struct ScalOp {
   using Params = ScalParams;
   static constexpr int kOrderedWaves = 1;  // (no constraint: 12 nodal fields do not fit 96 VGPRs)
+  // gor: the density as loaded, then (finish) Gamma / rho -- the only thing the edge formula wants of the density,
+  // a node's own quantity: divided once per node instead of twice per edge evaluation (same operation, same bits)
   struct Node {
-    double x[3], g[3], u[3], q, rho, gam;
+    double x[3], g[3], u[3], q, gor, gam;
   };
+  __device__ static __forceinline__ void finish(Node &a) { a.gor = a.gam / a.gor; }
   __device__ static __forceinline__ Node load(const Params &P, int n)
   {
     Node a;
@@ -129,8 +134,9 @@ struct ScalOp {
     a.g[0] = P.f.dqdx.x[n]; a.g[1] = P.f.dqdx.y[n]; a.g[2] = P.f.dqdx.z[n];
     a.u[0] = P.f.velocity.x[n]; a.u[1] = P.f.velocity.y[n]; a.u[2] = P.f.velocity.z[n];
     a.q = P.f.scalar_q[n];
-    a.rho = P.f.density[n];
+    a.gor = P.f.density[n];
     a.gam = P.f.diff_flux_coeff[n];
+    finish(a);
     return a;
   }
   // src/AssembleScalarEdgeSolverAlgorithm.C:320-329
@@ -190,7 +196,7 @@ struct ScalOp {
     }
     const double inv_axdx = 1.0 / axdx;
     const double viscIp = 0.5 * (L.gam + R.gam);
-    const double diffIp = 0.5 * (L.gam / L.rho + R.gam / R.rho);
+    const double diffIp = 0.5 * (L.gor + R.gor);  // (gor = Gamma / rho, see Node)
     const double pe = fabs(udotx) / (diffIp + small);
     double pecfac;
     if (P.o.peclet_kind == NALU_GPU_PECLET_CLASSIC) {
@@ -1262,6 +1268,7 @@ __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_
       double *po = reinterpret_cast<double *>(&own);
 #pragma unroll
       for (int f = 0; f < NF; ++f) po[f] = ldsN[f * 64 + lane];
+      Op::finish(own);
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
         double *pe = reinterpret_cast<double *>(&E[L::slot(k)]);
@@ -1350,6 +1357,7 @@ __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_
       const double *src = ldsAll + v * L::kDoubles + cur * NFP * 64;
 #pragma unroll
       for (int f = 0; f < NF; ++f) pn[f] = src[f * 64 + lane];
+      Op::finish(nb);
       return nb;
     };
     // (GY > 1) the far edge of a wave at an end of its group, then at once the NEXT step's far row into the
@@ -1522,10 +1530,12 @@ __global__ __launch_bounds__(QROWS * NW) void k_assemble_entries(SellView A, typ
           double *po = reinterpret_cast<double *>(&own);
 #pragma unroll
           for (int f = 0; f < NF; ++f) po[f] = ldsOwn[f * QROWS + lane];
+          Op::finish(own);  // (ldsOwn holds the fields as they are in memory)
           if (inQ) {
             double *pn = reinterpret_cast<double *>(&nb);
 #pragma unroll
             for (int f = 0; f < NF; ++f) pn[f] = ldsOwn[f * QROWS + (c - qBase)];
+            Op::finish(nb);
           }
           const bool isR = (tag >> 31) != 0;
           double lhs[4], rh[2];
