@@ -179,7 +179,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dTags); NG_FREE(h->dDiagPos); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
-  NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dBurst); NG_FREE(h->dMarch); NG_FREE(h->dMarchGroups); NG_FREE(h->dMarchSingles); NG_FREE(h->dMarchGroupsP); NG_FREE(h->dMarchSinglesP); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
+  NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dBurst); NG_FREE(h->dMarch); NG_FREE(h->dMarchGroups); NG_FREE(h->dMarchSingles); NG_FREE(h->dMarchGroupsP); NG_FREE(h->dMarchSinglesP); NG_FREE(h->dRowLen); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   for (auto &fd : h->flow) {
     NG_FREE(fd.dTicket); NG_FREE(fd.dChunks); NG_FREE(fd.dRowOf); NG_FREE(fd.dPubOf); NG_FREE(fd.dXch); NG_FREE(fd.dCode); NG_FREE(fd.dSteps); NG_FREE(fd.dSrc); NG_FREE(fd.dVal);
@@ -720,6 +720,18 @@ __global__ void k_slice_order(int nSlices, const long long *sliceOff, const int 
   ordWord[s] = word;
 }
 
+// entries of every row before its padding (the k-th entry of a row is its k-th CSR entry: padding comes last)
+__global__ __launch_bounds__(SELL_C) void k_row_len(const long long *__restrict__ sliceOff,
+                                                     const int *__restrict__ sliceWidth,
+                                                     const unsigned *__restrict__ tags, int *__restrict__ rowLen)
+{
+  const int s = blockIdx.x, w = sliceWidth[s];
+  const long long pos0 = sliceOff[s] + threadIdx.x;
+  int len = 0;
+  for (int k = 0; k < w; ++k) len += tags[pos0 + (long long)k * SELL_C] != TAG_PAD;
+  rowLen[(size_t)s * SELL_C + threadIdx.x] = len;
+}
+
 __global__ __launch_bounds__(SELL_C) void k_find_diag(int nRows, const long long *sliceOff,
                                                        const int *sliceWidth, const unsigned *tags,
                                                        long long *diagPos)
@@ -957,6 +969,11 @@ extern "C" int nalu_gpu_finalize(nalu_gpu_linsys *h)
       k_slice_order<<<(h->nSlices + 255) / 256, 256, 0, h->stream>>>(h->nSlices, h->dSliceOff, h->dSliceWidth,
                                                                       h->dKOff, h->dTBase, h->dTMul,
                                                                       h->dOrdWord, on);
+    NG_HIP(hipGetLastError());
+  }
+  if (h->nSlices > 0 && h->maxSliceWidth > LONG_ROW_W) {  // skewed rows: SpMV's long-row path needs the row lengths
+    NG_HIP(hipMalloc(&h->dRowLen, sizeof(int) * (size_t)h->nSlices * SELL_C));
+    k_row_len<<<h->nSlices, SELL_C, 0, h->stream>>>(h->dSliceOff, h->dSliceWidth, h->dTags, h->dRowLen);
     NG_HIP(hipGetLastError());
   }
   if (h->nSlices > 0 && h->maxSliceWidth <= BURST_W) {

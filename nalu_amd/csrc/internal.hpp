@@ -110,7 +110,15 @@ struct SellView {
   const unsigned char *edgeOwned;
   int nSlices;
   int nRows;
+  // entries of every stored row before its padding; null unless some slice is wider than LONG_ROW_W (SpMV then
+  // takes the slices wider than that through its long-row path)
+  const int *rowLen;
 };
+
+// SELL-256 pads a slice to its longest row.  Hex8 edge / element graphs have at most 7 / 27 entries per row; a
+// slice wider than this has a skewed row (a hub node, a constraint row) and SpMV must not walk the padding of
+// its other 255 rows (solve.hip: long_slice_sum)
+constexpr int LONG_ROW_W = 32;
 
 struct EventPair {
   hipEvent_t a, b;
@@ -227,6 +235,7 @@ struct nalu_gpu_linsys {
   int nMarchGroups = 0, nMarchSingles = 0;
   int *dMarchGroupsP = nullptr;  // every pattern run in groups of up to four adjacent lines, -1 = no member (lagpf kernel)
   int nMarchGroupsP = 0;
+  int *dRowLen = nullptr;         // SellView::rowLen
   int *dMarchSinglesP = nullptr;  // the pattern runs without a neighbouring line to group with
   int nMarchSinglesP = 0;
   int marchGY = 4;               // lines per group of dMarchGroupsP (4 or 8; NG_ASM_LAG_GY)
@@ -407,6 +416,7 @@ inline SellView sell_view(const nalu_gpu_linsys *h)
   v.nMarchPat = h->nMarchPat;
   v.marchXcdRun = h->marchXcdRun;
   v.edgeOwned = h->dEdgeOwned;
+  v.rowLen = h->dRowLen;
   v.nSlices = h->nSlicesOwned;  // the solver's view: owned rows only
   v.nRows = h->nOwned;
   return v;

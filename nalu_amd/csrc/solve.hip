@@ -255,6 +255,48 @@ __device__ __forceinline__ double row_sum(const SellView &A, long long pos, int 
   return sum;
 }
 
+// The long-row path: a slice wider than LONG_ROW_W has a skewed row (SELL-256 pads a slice to its longest row,
+// and the plain loop would walk that padding for all 256 rows).  Every row's first LONG_ROW_W entries are summed
+// by its own thread in entry order, up to the row's length; the rest of a longer row is summed by the whole
+// workgroup, thread t taking entries LONG_ROW_W + t, + 256, ..., and added in a fixed tree (wave shuffle tree,
+// the four wave sums in order).  Deterministic; for the rows longer than LONG_ROW_W the summation order is
+// not the CSR loop's (<= 1e-12 against the oracle instead of bit for bit).  North star's "general fallback" for
+// skewed rows: time is bounded by the entries that exist; the storage of such a slice stays padded.
+template <bool DINV>
+__device__ __forceinline__ double long_slice_sum(const SellView &A, long long so, int row,
+                                                 const double *__restrict__ x, const double *__restrict__ dinv)
+{
+  __shared__ int sLen[SELL_C];
+  __shared__ double sPart[SELL_C / 64];
+  const int t = threadIdx.x;
+  const int len = row < A.nRows ? A.rowLen[row] : 0;
+  sLen[t] = len;
+  double sum = 0.0;
+  const int n1 = min(len, LONG_ROW_W);
+  for (int k = 0; k < n1; ++k) {
+    const long long pos = so + (long long)k * SELL_C + t;
+    const int c = A.cols[pos];
+    sum += A.vals[pos] * (DINV ? dinv[c] * x[c] : x[c]);
+  }
+  __syncthreads();
+  for (int r = 0; r < SELL_C; ++r) {  // (workgroup-uniform: the lengths are in LDS)
+    const int lr = sLen[r];
+    if (lr <= LONG_ROW_W) continue;
+    double part = 0.0;
+    for (int k = LONG_ROW_W + t; k < lr; k += SELL_C) {
+      const long long pos = so + (long long)k * SELL_C + r;
+      const int c = A.cols[pos];
+      part += A.vals[pos] * (DINV ? dinv[c] * x[c] : x[c]);
+    }
+    part = wave_sum(part);
+    if ((t & 63) == 0) sPart[t >> 6] = part;
+    __syncthreads();
+    if (t == r) sum += ((sPart[0] + sPart[1]) + sPart[2]) + sPart[3];
+    __syncthreads();
+  }
+  return sum;
+}
+
 // One workgroup per slice, dispatched so that the eight XCDs sweep the matrix as ONE
 // streaming front (xcd_run): measured on MI355X at 256^3 this reads 5.7 TB/s against
 // 4.4 TB/s for per-XCD contiguous chunks marched by a capped grid (profiles/).  With DOT the
@@ -290,7 +332,9 @@ __global__ __launch_bounds__(SELL_C) void k_spmv(SellView A, const double *__res
   // waves of every slice at 256^3: 0.270 -> 0.2xx ms).
   const BurstRow *X = (A.burst && mask != 0ULL) ? &A.burst[s].irr[wave] : nullptr;
   // (not for a row with more than BURST_NE edges or with other graph entries: bits 16-24 of info)
-  if (X && X->lane < 64u && (X->info >> 16) == 0u && mask == (1ULL << X->lane)) {
+  if (A.rowLen && A.sliceWidth[s] > LONG_ROW_W) {  // (workgroup-uniform) a slice with a skewed row
+    sum = long_slice_sum<DINV>(A, so, row, x, dinv);
+  } else if (X && X->lane < 64u && (X->info >> 16) == 0u && mask == (1ULL << X->lane)) {
     constexpr int WMAX = BURST_W;
     const int w = A.sliceWidth[s];
     const int *off = A.kOff + so / SELL_C;

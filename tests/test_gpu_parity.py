@@ -292,6 +292,66 @@ def test_dot_product_is_the_oracles_tree_sum_bit_for_bit(G, torch, oracle, n):
     assert abs(got - oracle.dot(a, b)) <= 1e-12 * np.abs(a * b).sum()
 
 
+def test_skewed_row_takes_the_long_row_spmv_path(G, torch, oracle):
+    """A graph with a hub node (a row of 402 entries among rows of 3): SELL-256 pads the hub's slice to its
+    width, and SpMV takes that slice through its long-row path (every row's first 32 entries by its own thread
+    in entry order, the rest of the hub row by the whole workgroup in a fixed tree) -- north_star's general
+    fallback for skewed rows.  Against the oracle: the assembled matrix bit for bit (bulk sumInto of 2 x 2 edge
+    blocks + a nodal mass), SpMV bit for bit on every row but the hub's (<= 1e-13 there: another summation
+    order), Jacobi-CG and GMRES histories to 1e-10."""
+    n, hub = 3000, 777
+    rng = np.random.RandomState(5)
+    chain = np.stack([np.arange(n - 1), np.arange(1, n)], axis=1)
+    spokes = np.array([j for j in range(3, n, 7) if abs(j - hub) > 1][:400])
+    star = np.stack([np.minimum(hub, spokes), np.maximum(hub, spokes)], axis=1)
+    edges = np.ascontiguousarray(np.concatenate([chain, star]).astype(np.int32))
+    edges = edges[np.lexsort((edges[:, 1], edges[:, 0]))]
+    a = 0.5 + rng.uniform(0, 1, len(edges))
+    lhs = np.stack([a, -a, -a, a], axis=1).reshape(-1, 2, 2)
+    rhs = rng.uniform(-1, 1, (len(edges), 2))
+    mass, mrhs = 0.2 + rng.uniform(0, 1, n), rng.uniform(-1, 1, n)
+    nodes = np.arange(n, dtype=np.int32).reshape(-1, 1)
+    ls = oracle.LinSys(1, n)
+    ls.add_connections(edges)
+    ls.finalize()
+    ls.zero()
+    for e in range(len(edges)):
+        ls.sum_into(edges[e], rhs[e], lhs[e].ravel())
+    for i in range(n):
+        ls.sum_into([i], [mrhs[i]], [mass[i]])
+    g = G.GpuLinearSystem()
+    g.beginLinearSystemConstruction(n)
+    g.buildEdgeToNodeGraph(edges)
+    g.finalizeLinearSystem()
+    li = g.layout_info()
+    assert li["max_slice_width"] == 403, li  # the hub: itself + 2 chain neighbours + 400 spokes
+    t = lambda v: torch.as_tensor(np.ascontiguousarray(v), dtype=torch.float64, device="cuda:0")
+    g.zeroSystem()
+    g.sumIntoBatch(g.createScatterPlan(edges), t(rhs), t(lhs))
+    g.sumIntoBatch(g.createScatterPlan(nodes), t(mrhs.reshape(-1, 1)), t(mass.reshape(-1, 1, 1)))
+    g.loadComplete()
+    rp, ci, v = ls.owned_csr()
+    grp, gci = g.graph()
+    assert np.array_equal(grp, rp) and np.array_equal(gci, ci)
+    assert np.array_equal(g.matrix_values(), v) and np.array_equal(g.rhs(), ls.owned_rhs())
+    x = rng.uniform(-1, 1, n)
+    y = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    g.spmv(t(x), y)
+    g.synchronize()
+    got, want = y.cpu().numpy(), ls.spmv(x)
+    rest = np.arange(n) != hub
+    assert np.array_equal(got[rest], want[rest])
+    assert abs(got[hub] - want[hub]) <= 1e-13 * np.abs(v[rp[hub]:rp[hub + 1]]).sum()
+    for method, kw in (("cg", dict(tolerance=1e-10, max_iterations=300)),
+                       ("gmres", dict(tolerance=1e-10, max_iterations=200, kspace=50))):
+        ref = ls.solve(method, "jacobi", **kw)
+        xout = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+        g.solve(G.LinearSolverConfig(method=method, preconditioner="jacobi", **kw), xout)
+        assert g.linearSolveIterations == ref["iters"] and ref["iters"] < kw["max_iterations"]
+        assert np.abs(g.history - ref["history"]).max() <= TOL_SOLVE
+        assert rel_err(xout.cpu().numpy(), ref["x"]) <= TOL_SOLVE
+
+
 def test_solve_zero_rhs_and_reuse(G, torch, oracle):
     c = Case(oracle, 6)
     d = c.dev(torch)
