@@ -503,9 +503,13 @@ def main():
         asm_parts = [f"k_assemble_rows<{op}>"]
         if a.mode == "rows" and layout["assembly_variant"] in (4, 5, 6) and (layout["assembly_variant"] >= 5 or not scalar):
             main = {4: "k_assemble_rows_march", 5: "k_assemble_rows_lag", 6: "k_assemble_rows_lagpf"}[layout["assembly_variant"]]
+            rest = ("the rest as tail workgroups of the same launch (burst form)" if layout["assembly_variant"] == 6
+                    else "k_assemble_rows_burst for the rest")
             asm_kernel = (f"{main}<{op}> over {layout['march_runs']} runs of slices "
-                          f"({layout['march_slices']} of {layout['n_slices']} slices) + k_assemble_rows_burst for the rest")
+                          f"({layout['march_slices']} of {layout['n_slices']} slices) + {rest}")
             asm_parts = [f"{main}<{op}>", f"k_assemble_rows_burst<{op}>"]
+            if layout["assembly_variant"] == 6 and asm_parts[1] not in pmc:
+                asm_parts = asm_parts[:1]  # (one launch: the counters of the burst-form workgroups are in it)
         spmv_name = "k_spmv<DINV>" if scalar else "k_spmv<DOT>"
         spmv_traffic = traffic_of(pmc, [spmv_name])
         asm_traffic = traffic_of(pmc, asm_parts) if a.mode == "rows" else None
