@@ -1087,11 +1087,14 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_lag(SellView A, typ
 // bit-identical.
 // GY = 1: a workgroup = the four quarters of one run; each wave owns its LDS region: no barrier, no flags; the
 // y neighbours' rows are loads (B).
-// GY = 4: a workgroup = the same quarter of FOUR runs of adjacent lines (the groups of NG_ASM_LAG_GROUPS); the
-// nodal part of a wave's region is double-buffered and the waves read their y neighbours' rows out of the
-// NEIGHBOURING WAVE'S region (one barrier per step, right behind the wait (A): every wave's prefetch has landed
-// and nobody reads the buffer the next prefetch overwrites).  A row is then fetched from HBM once per group
-// and by the two groups next door, and the y neighbours hold no registers.
+// GY = 4 (the default; 8: 512-thread workgroups, NG_ASM_LAG_GY): a workgroup = the same quarter of GY runs of
+// adjacent lines (finalize: dMarchGroupsP, groups of 2 .. GY lines; single lines take GY = 1); the nodal part of
+// a wave's region is double-buffered and the waves read their y neighbours' rows out of the NEIGHBOURING WAVE'S
+// region (one barrier per step, right behind the wait (A): every wave's prefetch has landed and nobody reads
+// the buffer the next prefetch overwrites).  A row is then fetched from HBM once per group and by the two
+// groups next door, and the y neighbours hold no registers.  The far row of a wave at an end of its group --
+// the one load that misses the L2 -- is issued right after the edge that used the previous one (see early4),
+// not with (B).  The workgroups behind the last item assemble the slices outside the runs (burst_slice).
 // Edge ids of the prefetch follow the regular rows' pattern (id = tb + row); a wave's irregular row whose ids
 // do not, and a wave at the very end of the edge array (a 16-byte load would leave it), load those edges
 // themselves.
