@@ -249,8 +249,16 @@ __device__ __forceinline__ double flow_poll(const double *p, int *err, int maxPo
 // the entry codes into LDS ring slots (a slot that always holds 0.0 for entries of other chunks and
 // for padding), count and locate the entries of other chunks, and pad every row to W entries, so that
 // the consumer's usual path has no data-dependent branch.
-template <bool FWD, int D, int W, int GB>
-__global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView F, const int *__restrict__ done,
+// NC = 2 (round 3): TWO consumer waves take the chunk's steps in turn (wave 0 the even steps, the last wave the odd
+// ones).  A step's chain of dependent operations -- the previous step's values out of the LDS ring, W
+// multiply-subtracts, the new values back into the ring -- is a third of the ~150 instructions a step costs one
+// wave; the rest (the step's rows out of the staging ring, the look-ahead loads of values of other chunks, the
+// bookkeeping) does not depend on the previous step, and the other wave now does it for ITS next step meanwhile.
+// The hand-over is the `consumed` counter the publisher already follows: a wave computes step s when the rows
+// before off(s) are in the ring (acquire), and releases off(s + 1) after it.  Same operations in the same order
+// per row: bit-identical to NC = 1 and to the sequential sweep.
+template <bool FWD, int D, int W, int GB, int NC>
+__global__ __launch_bounds__(64 * (2 + FLOW_LOADERS + NC - 1)) void k_flow_sweep(FlowView F, const int *__restrict__ done,
                                                                         const double *in,
                                                                         const double *__restrict__ dinv, double *xch,
                                                                         double *out, int *err)
@@ -258,6 +266,10 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
   using Cfg = FlowCfg<D, W, GB>;
   constexpr int NSR = Cfg::NSR, NG = Cfg::NG, GROUP = Cfg::GROUP, WQ = W / 4;
   static_assert(W % 4 == 0 && D % 2 == 0, "ring slots are packed four to a word; two stages alternate");
+  static_assert(NC == 1 || NC == 2, "one or two consumer waves");
+  // (a consumer asks for the staged rows of its D-th next step: NC D + 1 steps ahead of the one it computes; the
+  // loaders can only stage them while the publisher is at most NSR - GROUP rows behind that)
+  static_assert((NC * D + 1) * 64 + GROUP <= NSR + 1 || NC == 1, "the staging ring is too small for two consumers");
   extern __shared__ double flowLds[];
   // The chunk of this workgroup: the next one of the schedule's order at the moment the workgroup
   // STARTS (a ticket drawn from a counter that every workgroup of every launch draws from exactly
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
     return;
   }
 
-  if (wave > 1) {  // ---- loaders
+  if (wave > 1 && wave < 2 + FLOW_LOADERS) {  // ---- loaders
     // One memory round trip per group of GB x 64 rows: the row numbers of a wave's next group are
     // loaded with the data of the current one, and all loads are issued before the wave waits for
     // the ring slots to become free.
@@ -429,9 +441,11 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
     return;
   }
 
-  // ---- consumer: its instruction stream is the sweep's critical path, the other waves of the CU yield
+  // ---- consumer(s): their instruction stream is the sweep's critical path, the other waves of the CU yield
   __builtin_amdgcn_s_setprio(3);
   const int nSteps = C.nSteps;
+  const int cid = wave == 0 ? 0 : 1;                   // which consumer (NC = 2: the last wave is the second one)
+  auto G = [&](int i) { return NC * i + cid; };        // the consumer's i-th step
   // first rows of steps vbase .. vbase + 63, one per lane (uniform reads without a memory access)
   int vbase = 0;
   int vstep = sSteps[min(lane, nSteps)];
@@ -586,41 +600,58 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS)) void k_flow_sweep(FlowView
 
   double ex0[D], ex1[D];
   Stage st[2];
-  if (F.trace && lane == 0) F.trace[8 * chunkId] = wall_clock64();
+  // (NC = 2) the rows before step s are in the ring: the other consumer has released them
+  auto wait_prev = [&](int s) {
+    if (NC == 1 || s == 0) return;
+    const int need = off(s);
+    // (polls back to back: a lower priority or a sleep between polls changes nothing, measured)
+    int spins = 0;
+    while (__hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+      if (__hip_atomic_load(abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) || ++spins >= FLOW_MAX_LDS_SPIN) {
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(abortFlag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        dead = true;
+        return;
+      }
+    }
+  };
+  const bool tracing = F.trace && lane == 0 && cid == 0;
+  if (tracing) F.trace[8 * chunkId] = wall_clock64();
 #pragma unroll
-  for (int j = 0; j < D; ++j) prefetch(j, ex0[j], ex1[j]);
-  load_stage(0, st[0]);
-  for (int sb = 0; sb < nSteps && !dead; sb += D) {
-    if (sb + 2 * D + 1 - vbase > 63) {  // this round reads the offsets of steps sb .. sb + 2 D + 1
-      vbase = sb;
-      vstep = sSteps[min(sb + lane, nSteps)];
+  for (int j = 0; j < D; ++j) prefetch(G(j), ex0[j], ex1[j]);
+  load_stage(G(0), st[0]);
+  for (int ib = 0; G(ib) < nSteps && !dead; ib += D) {
+    if (G(ib + 2 * D) + 1 - vbase > 63) {  // this round reads the offsets of steps G(ib) .. G(ib + 2 D) + 1
+      vbase = G(ib);
+      vstep = sSteps[min(vbase + lane, nSteps)];
     }
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      const int s = sb + j;
-      load_stage(s + 1, st[(j + 1) & 1]);
+      const int i = ib + j, s = G(i);
+      load_stage(G(i + 1), st[(j + 1) & 1]);
       ring_free(st[j & 1].end);
       if (!dead) {
         const Stage &S = st[j & 1];
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(late(S, ex0[j], ex1[j])) != 0, 0))
           recover([&]() {
 #pragma unroll
-            for (int jj = 0; jj < D; ++jj) prefetch(s + jj, ex0[(j + jj) % D], ex1[(j + jj) % D]);
+            for (int jj = 0; jj < D; ++jj) prefetch(G(i + jj), ex0[(j + jj) % D], ex1[(j + jj) % D]);
             bool miss = false;
 #pragma unroll
-            for (int jj = 0; jj < D; ++jj) miss |= missing(s + jj, ex0[(j + jj) % D], ex1[(j + jj) % D]);
+            for (int jj = 0; jj < D; ++jj) miss |= missing(G(i + jj), ex0[(j + jj) % D], ex1[(j + jj) % D]);
             return miss;
           });
-        compute(S, ex0[j], ex1[j]);
+        wait_prev(s);
+        if (!dead) compute(S, ex0[j], ex1[j]);
       }
-      if (s < nSteps && !dead)  // hands the step's rows to the publisher
+      if (s < nSteps && !dead)  // hands the step's rows to the publisher (and to the other consumer)
         __hip_atomic_store(consumed, st[j & 1].end, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      prefetch(s + D, ex0[j], ex1[j]);
+      prefetch(G(i + D), ex0[j], ex1[j]);
     }
-    if (F.trace && lane == 0 && sb == 0) F.trace[8 * chunkId + 1] = wall_clock64();
-    if (F.trace && lane == 0 && sb <= nSteps / 2) F.trace[8 * chunkId + 2] = wall_clock64();
+    if (tracing && ib == 0) F.trace[8 * chunkId + 1] = wall_clock64();
+    if (tracing && G(ib) <= nSteps / 2) F.trace[8 * chunkId + 2] = wall_clock64();
   }
-  if (F.trace && lane == 0) {
+  if (tracing) {
     F.trace[8 * chunkId + 3] = wall_clock64();
     F.trace[8 * chunkId + 4] = trPollTicks;
     F.trace[8 * chunkId + 5] = trPolls;
@@ -802,13 +833,17 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *o
     NG_HIP(hipMemsetAsync(F.trace, 0, sizeof(long long) * 8 * (size_t)fd.nChunks, h->stream));
   }
   int *err = (int *)(h->dReduce + REDUCE_CAP) + 2;
-  const dim3 block(64 * (2 + FLOW_LOADERS));
+  const dim3 block(64 * (2 + FLOW_LOADERS)), block2(64 * (3 + FLOW_LOADERS));
+  // two consumer waves for the 7-point rows at the default depth (NG_SGS_CONSUMERS=1: one)
+  const bool two = !(getenv("NG_SGS_CONSUMERS") && atoi(getenv("NG_SGS_CONSUMERS")) == 1);
   if (fd.depth == 4 && fd.wMax <= 4)
-    k_flow_sweep<FWD, 4, 4, 2><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
+    k_flow_sweep<FWD, 4, 4, 2, 1><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
+  else if (fd.wMax <= 4 && two)
+    k_flow_sweep<FWD, 2, 4, 2, 2><<<fd.nChunks, block2, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
   else if (fd.wMax <= 4)
-    k_flow_sweep<FWD, 2, 4, 2><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
+    k_flow_sweep<FWD, 2, 4, 2, 1><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
   else
-    k_flow_sweep<FWD, 2, 16, 1><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
+    k_flow_sweep<FWD, 2, 16, 1, 1><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
   NG_HIP(hipGetLastError());
   if (tracePath) {  // development aid: the last sweep's per-chunk clocks (100 MHz ticks), one file per direction
     std::vector<long long> t((size_t)fd.nChunks * 8);
@@ -919,12 +954,14 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     s = FlowSchedule();
   }
   NG_HIP(hipMalloc(&h->dFlowT, sizeof(double) * (size_t)n));
-  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
-  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
-  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
-  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
-  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 2, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
-  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 2, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 4, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 4, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 2, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 2, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 2, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 2, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 2, 16, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
+  NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 2, 16, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   h->flowTiled = T.tiled;
   h->flowTile[0] = T.Q; h->flowTile[1] = T.P; h->flowTile[2] = T.By; h->flowTile[3] = T.Bz;
   h->flowState = 1;

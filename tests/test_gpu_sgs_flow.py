@@ -87,6 +87,10 @@ CASES = [
     ((256, 5, 4), False, {"NG_SGS_TILE": "2,2"}, True),
     ((33, 7, 19), False, {"NG_SGS_TILE": "8,16"}, True),
     ((64, 48, 40), False, {}, True),
+    # one consumer wave per chunk instead of the two that take the steps in turn (7-point rows, the default)
+    ((64, 48, 40), False, {"NG_SGS_CONSUMERS": "1"}, True),
+    ((33, 7, 19), False, {"NG_SGS_TILE": "8,16", "NG_SGS_CONSUMERS": "1"}, True),
+    ((256, 5, 4), False, {"NG_SGS_TILE": "2,2", "NG_SGS_DEPTH": "4"}, True),   # look-ahead of four steps: one consumer
     ((7, 6, 5), True, {}, False),
     ((12, 11, 10), True, {"NG_SGS_CHUNK": "128"}, False),
 ]
@@ -96,7 +100,8 @@ CASES = [
 def test_dataflow_sweeps_equal_level_sweeps_bit_for_bit(G, torch, oracle, dims, elem, env, tiled):
     m = oracle.BoxMesh(*dims)
     kw = dict(tolerance=1e-11, max_iterations=60, kspace=30)
-    with _Env(NG_SGS_MODE=None, NG_SGS_INPLACE=None, NG_SGS_TILE=None, NG_SGS_CHUNK=None):
+    with _Env(NG_SGS_MODE=None, NG_SGS_INPLACE=None, NG_SGS_TILE=None, NG_SGS_CHUNK=None, NG_SGS_CONSUMERS=None,
+              NG_SGS_DEPTH=None):
         with _Env(**env):
             g, ls = _system(G, oracle, m, elem, seed=3)
             res = {meth: _solve(G, g, meth, **kw) for meth in ("cg", "gmres")}
