@@ -199,12 +199,19 @@ struct FlowView {
   int maxPoll;   // polls of one value before a wave gives up (FLOW_MAX_POLL; NG_SGS_MAX_POLL: the tests' way to provoke it)
   unsigned long long *ticket;  // chunks handed out so far, over all launches of this sweep direction
   long long *trace;  // development aid (NG_SGS_TRACE): per chunk, clock at start / after the first step / at the end
+  long long *stepTrace;  // development aid (NG_SGS_TRACE_STEPS): per chunk and step: clock after the step, ticks in recover, in wait_prev
 };
 
 // D: steps of look-ahead for values of other chunks; W: entries per row at most (a multiple of 4);
 // GB: batches of 64 rows a loader wave has in flight; NSR: rows of the staging ring (a power of two:
 // D steps of look-ahead + a loader group + what the publisher may still hold)
 constexpr int flow_pow2(int v) { int p = 64; while (p < v) p *= 2; return p; }
+// (development aid, -DNG_FLOW_STEP_TRACE: NG_SGS_TRACE_STEPS=<path> dumps every chunk's step timeline, scripts/flowsteps.py)
+#ifdef NG_FLOW_STEP_TRACE
+constexpr bool kStepTrace = true;
+#else
+constexpr bool kStepTrace = false;
+#endif
 template <int D, int W, int GB>
 struct FlowCfg {
   static constexpr int GROUP = GB * 64;
@@ -298,6 +305,7 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS + NC - 1)) void k_flow_sweep
   int *abortFlag = consumed + 1;
   int *published = abortFlag + 1;      // rows the publisher has stored: their staging rows and ring slots are free
   int *sSteps = abortFlag + 3;         // [nSteps + 1]: first row of every step
+  long long *sTs = (long long *)(((size_t)(sSteps + F.maxSteps + 2) + 7) & ~(size_t)7);  // (NG_SGS_TRACE_STEPS only)
   const FlowChunk C = F.chunks[chunkId];
   if (threadIdx.x < NG + 4) ready[threadIdx.x] = 0;
   if (threadIdx.x < 2) tring[ring + threadIdx.x] = 0.0;
@@ -632,7 +640,9 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS + NC - 1)) void k_flow_sweep
       ring_free(st[j & 1].end);
       if (!dead) {
         const Stage &S = st[j & 1];
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(late(S, ex0[j], ex1[j])) != 0, 0))
+        long long trRec = 0, trPrev = 0;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(late(S, ex0[j], ex1[j])) != 0, 0)) {
+          if (kStepTrace && F.stepTrace) trRec = wall_clock64();
           recover([&]() {
 #pragma unroll
             for (int jj = 0; jj < D; ++jj) prefetch(G(i + jj), ex0[(j + jj) % D], ex1[(j + jj) % D]);
@@ -641,8 +651,17 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS + NC - 1)) void k_flow_sweep
             for (int jj = 0; jj < D; ++jj) miss |= missing(G(i + jj), ex0[(j + jj) % D], ex1[(j + jj) % D]);
             return miss;
           });
+          if (kStepTrace && F.stepTrace) trRec = wall_clock64() - trRec;
+        }
+        if (kStepTrace && F.stepTrace) trPrev = wall_clock64();
         wait_prev(s);
+        if (kStepTrace && F.stepTrace) trPrev = wall_clock64() - trPrev;
         if (!dead) compute(S, ex0[j], ex1[j]);
+        if (kStepTrace && F.stepTrace && lane == 0 && s < nSteps) {
+          sTs[3 * s] = wall_clock64();
+          sTs[3 * s + 1] = trRec;
+          sTs[3 * s + 2] = trPrev;
+        }
       }
       if (s < nSteps && !dead)  // hands the step's rows to the publisher (and to the other consumer)
         __hip_atomic_store(consumed, st[j & 1].end, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -651,6 +670,9 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS + NC - 1)) void k_flow_sweep
     if (tracing && ib == 0) F.trace[8 * chunkId + 1] = wall_clock64();
     if (tracing && G(ib) <= nSteps / 2) F.trace[8 * chunkId + 2] = wall_clock64();
   }
+  if (kStepTrace && F.stepTrace)
+    for (int i = lane; G(i) < nSteps; i += 64)
+      for (int c = 0; c < 3; ++c) F.stepTrace[((size_t)chunkId * F.maxSteps + G(i)) * 3 + c] = sTs[3 * G(i) + c];
   if (tracing) {
     F.trace[8 * chunkId + 3] = wall_clock64();
     F.trace[8 * chunkId + 4] = trPollTicks;
@@ -832,18 +854,27 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *o
     NG_HIP(hipMalloc(&F.trace, sizeof(long long) * 8 * (size_t)fd.nChunks));
     NG_HIP(hipMemsetAsync(F.trace, 0, sizeof(long long) * 8 * (size_t)fd.nChunks, h->stream));
   }
+  F.stepTrace = nullptr;
+  const char *stepPath = kStepTrace ? getenv("NG_SGS_TRACE_STEPS") : nullptr;
+  const size_t stepN = (size_t)fd.nChunks * (size_t)fd.maxSteps * 3;
+  size_t ldsBytes = fd.ldsBytes;
+  if (stepPath) {
+    NG_HIP(hipMalloc(&F.stepTrace, sizeof(long long) * stepN));
+    NG_HIP(hipMemsetAsync(F.stepTrace, 0, sizeof(long long) * stepN, h->stream));
+    ldsBytes += 8 + 24 * (size_t)(fd.maxSteps + 1);
+  }
   int *err = (int *)(h->dReduce + REDUCE_CAP) + 2;
   const dim3 block(64 * (2 + FLOW_LOADERS)), block2(64 * (3 + FLOW_LOADERS));
   // two consumer waves for the 7-point rows at the default depth (NG_SGS_CONSUMERS=1: one)
   const bool two = !(getenv("NG_SGS_CONSUMERS") && atoi(getenv("NG_SGS_CONSUMERS")) == 1);
   if (fd.depth == 4 && fd.wMax <= 4)
-    k_flow_sweep<FWD, 4, 4, 2, 1><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
+    k_flow_sweep<FWD, 4, 4, 2, 1><<<fd.nChunks, block, ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
   else if (fd.wMax <= 4 && two)
-    k_flow_sweep<FWD, 2, 4, 2, 2><<<fd.nChunks, block2, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
+    k_flow_sweep<FWD, 2, 4, 2, 2><<<fd.nChunks, block2, ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
   else if (fd.wMax <= 4)
-    k_flow_sweep<FWD, 2, 4, 2, 1><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
+    k_flow_sweep<FWD, 2, 4, 2, 1><<<fd.nChunks, block, ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
   else
-    k_flow_sweep<FWD, 2, 16, 1, 1><<<fd.nChunks, block, fd.ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
+    k_flow_sweep<FWD, 2, 16, 1, 1><<<fd.nChunks, block, ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
   NG_HIP(hipGetLastError());
   if (tracePath) {  // development aid: the last sweep's per-chunk clocks (100 MHz ticks), one file per direction
     std::vector<long long> t((size_t)fd.nChunks * 8);
@@ -859,6 +890,21 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *o
 
     }
   }
+  if (stepPath) {
+    std::vector<long long> t(stepN);
+    NG_HIP(hipStreamSynchronize(h->stream));
+    NG_HIP(hipMemcpy(t.data(), F.stepTrace, sizeof(long long) * stepN, hipMemcpyDeviceToHost));
+    (void)hipFree(F.stepTrace);
+    bool any = false;
+    for (size_t i = 0; i < stepN && !any; i += 3) any = t[i] != 0;
+    FILE *f = any ? fopen((std::string(stepPath) + (FWD ? ".fwd" : ".bwd")).c_str(), "wb") : nullptr;
+    if (f) {
+      const long long hdr[2] = {fd.nChunks, fd.maxSteps};
+      fwrite(hdr, sizeof(long long), 2, f);
+      fwrite(t.data(), sizeof(long long), stepN, f);
+      fclose(f);
+    }
+  }
   return NALU_GPU_OK;
 }
 
@@ -871,7 +917,7 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
   if (n == 0) return NALU_GPU_OK;
   int chunkRows = getenv("NG_SGS_CHUNK") ? atoi(getenv("NG_SGS_CHUNK")) : 1024;
   chunkRows = std::min(std::max(chunkRows, 64), 2048);
-  int By = 6, Bz = 6;  // (profiles/r2_sgsflow_tiles.json: 5 x 6 ... 6 x 7 are within 1 %)
+  int By = 6, Bz = 6;  // (profiles/r2_sgsflow_tiles.json; r3b_sgs_steps.txt: 5 x 6 is 3 % ahead at 256^3, 3-4 % behind at 64^3 / 128^3)
   if (const char *t = getenv("NG_SGS_TILE")) {
     if (sscanf(t, "%d,%d", &By, &Bz) != 2) By = Bz = 0;  // anything else: contiguous chunks only
   }
