@@ -301,7 +301,7 @@ struct nalu_gpu_linsys {
     unsigned long long *dTicket = nullptr;  // chunks drawn so far (k_flow_sweep: the chunk of a workgroup is its ticket)
     double *dXch = nullptr;  // exchange buffer: the rows other chunks read, in schedule order (nVisible)
     int nVisible = 0;
-    long long *dSrc = nullptr;  // SELL position of every entry's value (-1: pad)
+    unsigned char *dKFirst = nullptr;  // backward only: entry k of compact row p is the (kFirst[p] + k)-th of its matrix row
     double *dVal = nullptr;
     int nChunks = 0, wMax = 0, ring = 0, depth = 0, maxSteps = 0;
     long long nEnt = 0;

@@ -21,6 +21,7 @@
 // previous levels nearly contiguously, z is scattered back once.  Same operations in the same
 // order per row as before: bit-identical results.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -81,6 +82,25 @@ __global__ __launch_bounds__(256) void k_sgs_backward(SellView A, const int *__r
 
 // ---- level-major sweeps
 // values of the level-major blocks from the SELL matrix (compute(), once per solve)
+// the matrix values in the order of a dataflow schedule: one workgroup per chunk; entry k of compact row q is the
+// (kFirst + k)-th entry of its SELL row (FLOW_PAD: no entry, 0.0)
+__global__ __launch_bounds__(256) void k_flow_gather_vals(const FlowChunk *__restrict__ chunks, const int *__restrict__ rowOf,
+                                                           const unsigned char *__restrict__ kFirst,
+                                                           const int *__restrict__ code,
+                                                           const long long *__restrict__ sliceOff,
+                                                           const double *__restrict__ vals, double *__restrict__ out)
+{
+  const FlowChunk C = chunks[blockIdx.x];
+  for (int q = threadIdx.x; q < C.m; q += blockDim.x) {
+    const int i = rowOf[(size_t)C.rowOff + q];
+    const long long p0 = sliceOff[i / SELL_C] + i % SELL_C + (long long)(kFirst ? kFirst[(size_t)C.rowOff + q] : 0) * SELL_C;
+    for (int k = 0; k < C.w; ++k) {
+      const size_t idx = (size_t)(C.entOff + (long long)k * C.m + q);
+      out[idx] = code[idx] != FLOW_PAD ? vals[p0 + (long long)k * SELL_C] : 0.0;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_lm_gather_vals(long long n, const long long *__restrict__ src,
                                                          const double *__restrict__ vals, double *__restrict__ out)
 {
@@ -196,6 +216,7 @@ struct FlowView {
   int ringMask;  // LDS ring of in-chunk values: ring - 1, ring >= largest lookback + 64
   int maxSteps;  // most steps of any chunk (the step offsets of a chunk are copied to LDS)
   int nVisible;  // slots of the exchange buffer
+  int recoverAll;  // a recovery wait ends when the values of all D look-ahead steps are there (one consumer) / of its own step (two)
   int maxPoll;   // polls of one value before a wave gives up (FLOW_MAX_POLL; NG_SGS_MAX_POLL: the tests' way to provoke it)
   unsigned long long *ticket;  // chunks handed out so far, over all launches of this sweep direction
   long long *trace;  // development aid (NG_SGS_TRACE): per chunk, clock at start / after the first step / at the end
@@ -569,6 +590,7 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS + NC - 1)) void k_flow_sweep
   // on step by step would cost a memory round trip per step (and every chunk behind this one would
   // inherit that pace).  Instead ask again for the values of steps s .. s + D - 1, all of them at once,
   // until they are all there: one wait per D steps, and the loads that end it bring the values.
+  // (Two consumers, F.recoverAll = 0: until those of step s are there -- the other wave computes meanwhile.)
   auto recover = [&](auto &&refetch_missing) {
     const long long trT0 = F.trace ? wall_clock64() : 0;
     int spins = 0;
@@ -648,7 +670,8 @@ __global__ __launch_bounds__(64 * (2 + FLOW_LOADERS + NC - 1)) void k_flow_sweep
             for (int jj = 0; jj < D; ++jj) prefetch(G(i + jj), ex0[(j + jj) % D], ex1[(j + jj) % D]);
             bool miss = false;
 #pragma unroll
-            for (int jj = 0; jj < D; ++jj) miss |= missing(G(i + jj), ex0[(j + jj) % D], ex1[(j + jj) % D]);
+            for (int jj = 0; jj < D; ++jj)
+              if (jj == 0 || F.recoverAll) miss |= missing(G(i + jj), ex0[(j + jj) % D], ex1[(j + jj) % D]);
             return miss;
           });
           if (kStepTrace && F.stepTrace) trRec = wall_clock64() - trRec;
@@ -821,8 +844,8 @@ using FlowA2 = FlowCfg<2, 4, 2>;
 using FlowB = FlowCfg<2, 16, 1>;
 constexpr size_t FLOW_MAX_LDS = 96 * 1024;
 
-template <class T>
-int flow_upload(const std::vector<T> &v, T **dst)
+template <class V, class T>
+int flow_upload(const V &v, T **dst)
 {
   NG_HIP(hipMalloc(dst, sizeof(T) * std::max<size_t>(v.size(), 1)));
   NG_HIP(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
@@ -867,6 +890,10 @@ int flow_launch(nalu_gpu_linsys *h, const int *done, const double *in, double *o
   const dim3 block(64 * (2 + FLOW_LOADERS)), block2(64 * (3 + FLOW_LOADERS));
   // two consumer waves for the 7-point rows at the default depth (NG_SGS_CONSUMERS=1: one)
   const bool two = !(getenv("NG_SGS_CONSUMERS") && atoi(getenv("NG_SGS_CONSUMERS")) == 1);
+  // One consumer: a recovery wait that only asked for its own step would cost a memory round trip per step.  Two: the
+  // other wave computes meanwhile, and waiting for the second look-ahead step as well puts two more producer steps
+  // (0.8 us) into every hop (profiles/r3b_sgs_steps.txt; NG_SGS_RECOVER_ALL=1: the old behaviour; -1.5 ... -3 %)
+  F.recoverAll = getenv("NG_SGS_RECOVER_ALL") ? atoi(getenv("NG_SGS_RECOVER_ALL")) != 0 : !(two && fd.depth != 4 && fd.wMax <= 4);
   if (fd.depth == 4 && fd.wMax <= 4)
     k_flow_sweep<FWD, 4, 4, 2, 1><<<fd.nChunks, block, ldsBytes, h->stream>>>(F, done, in, h->dDinv, fd.dXch, out, err);
   else if (fd.wMax <= 4 && two)
@@ -923,8 +950,18 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
   }
   int hostThreads = getenv("NG_HOST_THREADS") ? atoi(getenv("NG_HOST_THREADS")) : (int)std::thread::hardware_concurrency();
   hostThreads = std::min(std::max(hostThreads, 2), 16);
-  std::vector<int> chunkOf;
-  FlowTiling T = flow_chunking(n, h->rowPtr.data(), h->colIdx.data(), chunkRows, By, Bz, chunkOf);
+  // (NG_SGS_VERBOSE: the phases of the set-up on stderr)
+  const bool verbose = env_not_zero("NG_SGS_VERBOSE");
+  auto tPrev = std::chrono::steady_clock::now();
+  auto phase = [&](const char *name) {
+    if (!verbose) return;
+    const auto tNow = std::chrono::steady_clock::now();
+    fprintf(stderr, "[nalu_gpu sgs set-up] %-28s %.3f s\n", name, std::chrono::duration<double>(tNow - tPrev).count());
+    tPrev = tNow;
+  };
+  FlowBuf<int> chunkOf;
+  FlowTiling T = flow_chunking(n, h->rowPtr.data(), h->colIdx.data(), chunkRows, By, Bz, chunkOf, hostThreads);
+  phase("chunking");
   FlowSchedule S[2];
   for (int attempt = 0; attempt < 2; ++attempt) {
     // both sweeps at once, each on half of the host threads (16 at most: a GPU's share of the node's cores)
@@ -947,8 +984,9 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     for (int dir = 0; dir < 2 && ok; ++dir) ok = S[dir].maxLookback + FLOW_STEP <= 4096;
     if (ok) break;
     if (!T.tiled) return NALU_GPU_OK;  // contiguous chunks are always a valid order: only the ring can fail
-    T = flow_chunking(n, h->rowPtr.data(), h->colIdx.data(), chunkRows, 0, 0, chunkOf);
+    T = flow_chunking(n, h->rowPtr.data(), h->colIdx.data(), chunkRows, 0, 0, chunkOf, hostThreads);
   }
+  phase("schedules (both sweeps)");
   for (int dir = 0; dir < 2; ++dir) {
     nalu_gpu_linsys::FlowDir &fd = h->flow[dir];
     const FlowSchedule &s = S[dir];
@@ -972,18 +1010,6 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
   for (int dir = 0; dir < 2; ++dir) {
     nalu_gpu_linsys::FlowDir &fd = h->flow[dir];
     FlowSchedule &s = S[dir];
-    // CSR entry -> position of its value in the SELL matrix
-    flow_parallel_for((int)s.chunks.size(), hostThreads, [&](int ic) {
-      const FlowChunk &C = s.chunks[(size_t)ic];
-      for (int q = 0; q < C.m; ++q) {
-        const int i = s.rowOf[(size_t)C.rowOff + q];
-        const long long so = h->hSliceOff[i / SELL_C] + i % SELL_C;
-        for (int k = 0; k < C.w; ++k) {
-          long long &e = s.src[(size_t)(C.entOff + (long long)k * C.m + q)];
-          if (e >= 0) e = so + (e - h->rowPtr[i]) * SELL_C;
-        }
-      }
-    });
     FlowChunk *dc = nullptr;
     NG_TRY(flow_upload(s.chunks, &dc));
     fd.dChunks = dc;
@@ -995,10 +1021,11 @@ int ensure_sgs_flow(nalu_gpu_linsys *h)
     NG_HIP(hipMemset(fd.dTicket, 0, sizeof(unsigned long long)));
     NG_TRY(flow_upload(s.code, &fd.dCode));
     NG_TRY(flow_upload(s.steps, &fd.dSteps));
-    NG_TRY(flow_upload(s.src, &fd.dSrc));
+    if (dir == 1) NG_TRY(flow_upload(s.kFirst, &fd.dKFirst));
     NG_HIP(hipMalloc(&fd.dVal, sizeof(double) * (size_t)fd.nEnt));
     s = FlowSchedule();
   }
+  phase("upload");
   NG_HIP(hipMalloc(&h->dFlowT, sizeof(double) * (size_t)n));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<true, 4, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
   NG_HIP(hipFuncSetAttribute((const void *)k_flow_sweep<false, 4, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_MAX_LDS));
@@ -1042,7 +1069,8 @@ int nalu_gpu::sgs_compute(nalu_gpu_linsys *h)
   if (n == 0) return NALU_GPU_OK;
   if (flow_active(h)) {  // the values in schedule order
     for (auto &fd : h->flow)
-      k_lm_gather_vals<<<(unsigned)((fd.nEnt + 255) / 256), 256, 0, h->stream>>>(fd.nEnt, fd.dSrc, h->dVals, fd.dVal);
+      k_flow_gather_vals<<<fd.nChunks, 256, 0, h->stream>>>((const FlowChunk *)fd.dChunks, fd.dRowOf, fd.dKFirst, fd.dCode,
+                                                            h->dSliceOff, h->dVals, fd.dVal);
     NG_HIP(hipGetLastError());
     return NALU_GPU_OK;
   }

@@ -88,8 +88,8 @@ static int check(const char *name, const Csr &A, int chunkRows, int By, int Bz)
       if (A.col[k] > i) s += A.val[k] * zRef[A.col[k]];
     zRef[i] = tRef[i] - s * dinv[i];
   }
-  std::vector<int> chunkOf;
-  FlowTiling T = flow_chunking(n, A.rowPtr.data(), A.col.data(), chunkRows, By, Bz, chunkOf);
+  FlowBuf<int> chunkOf;
+  FlowTiling T = flow_chunking(n, A.rowPtr.data(), A.col.data(), chunkRows, By, Bz, chunkOf, 3);
   int bad = 0;
   for (int dir = 0; dir < 2; ++dir) {
     const bool fwd = dir == 0;
@@ -123,7 +123,7 @@ static int check(const char *name, const Csr &A, int chunkRows, int By, int Bz)
               v = flow[(size_t)~code];
               if (std::isnan(v)) ++notReady;
             }
-            const double a = A.val[(size_t)S.src[idx]];
+            const double a = A.val[(size_t)(A.rowPtr[row] + (fwd ? 0 : S.kFirst[(size_t)C.rowOff + q]) + k)];
             acc = fwd ? acc - a * v : acc + a * v;
           }
           out[(size_t)(q - s0)] = fwd ? acc * dinv[row] : in[row] - acc * dinv[row];
