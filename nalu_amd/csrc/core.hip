@@ -179,7 +179,7 @@ extern "C" int nalu_gpu_destroy(nalu_gpu_linsys *h)
   NG_FREE(h->dTags); NG_FREE(h->dDiagPos); NG_FREE(h->dEdgeL); NG_FREE(h->dEdgeR); NG_FREE(h->dSlots);
   NG_FREE(h->dColorPerm); NG_FREE(h->dRhs); NG_FREE(h->dX); NG_FREE(h->dDinv);
   NG_FREE(h->dR); NG_FREE(h->dP); NG_FREE(h->dQ); NG_FREE(h->dW); NG_FREE(h->dT);
-  NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dBurst); NG_FREE(h->dMarch); NG_FREE(h->dMarchGroups); NG_FREE(h->dMarchSingles); NG_FREE(h->dMarchGroupsP); NG_FREE(h->dMarchSinglesP); NG_FREE(h->dRowLen); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
+  NG_FREE(h->dV); NG_FREE(h->dKry); NG_FREE(h->dPartials); NG_FREE(h->dSlicePartials); NG_FREE(h->dSliceLists); NG_FREE(h->dKOff); NG_FREE(h->dExMask); NG_FREE(h->dTBase); NG_FREE(h->dTMul); NG_FREE(h->dOrdWord); NG_FREE(h->dBurst); NG_FREE(h->dMarch); NG_FREE(h->dMarchGroups); NG_FREE(h->dMarchSingles); NG_FREE(h->dMarchGroupsP); NG_FREE(h->dMarchSinglesP); NG_FREE(h->dRowLen); NG_FREE(h->dExMaskT); NG_FREE(h->dSgsFwdRows); NG_FREE(h->dSgsBwdRows); NG_FREE(h->dLmFwdSrc); NG_FREE(h->dLmBwdSrc); NG_FREE(h->dLmFwdCol); NG_FREE(h->dLmBwdCol); NG_FREE(h->dLmTpos); NG_FREE(h->dLmFwdVal); NG_FREE(h->dLmBwdVal); NG_FREE(h->dLmDinvF); NG_FREE(h->dLmDinvB); NG_FREE(h->dLmR); NG_FREE(h->dLmT); NG_FREE(h->dLmZ); NG_FREE(h->dMcRows); for (auto &m : h->mc) { NG_FREE(m.dCol); NG_FREE(m.dK); NG_FREE(m.dVal); } NG_FREE(h->dAlphaHist); NG_FREE(h->dPRing); NG_FREE(h->dChebV); NG_FREE(h->dChebStart); NG_FREE(h->dReduce); NG_FREE(h->dScal);
   NG_FREE(h->dHist); NG_FREE(h->dH); NG_FREE(h->dCs); NG_FREE(h->dSn); NG_FREE(h->dG);
   for (auto &fd : h->flow) {
     NG_FREE(fd.dTicket); NG_FREE(fd.dChunks); NG_FREE(fd.dRowOf); NG_FREE(fd.dPubOf); NG_FREE(fd.dXch); NG_FREE(fd.dCode); NG_FREE(fd.dSteps); NG_FREE(fd.dKFirst); NG_FREE(fd.dVal);

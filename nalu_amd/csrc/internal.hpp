@@ -315,6 +315,16 @@ struct nalu_gpu_linsys {
   bool mcReady = false;
   std::vector<int> mcOff;
   int *dMcRows = nullptr;
+  // colour-major copy of the entries a colour's rows read in the forward ([0]: lower colours) and in the backward
+  // sweep ([1]: higher colours): per colour w x cnt values / columns (-1: none) / entry numbers inside the SELL row
+  struct McDir {
+    std::vector<long long> entOff;  // per colour
+    std::vector<int> width;
+    long long nEnt = 0;
+    int *dCol = nullptr;
+    unsigned short *dK = nullptr;
+    double *dVal = nullptr;
+  } mc[2];
 
   // Chebyshev preconditioner (solve.hip)
   double *dChebV = nullptr;      // nOwned
@@ -502,6 +512,7 @@ void sgs_flow_disable(nalu_gpu_linsys *h);
 int apply_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone);
 int sgs_compute(nalu_gpu_linsys *h);
 int ensure_mc_colors(nalu_gpu_linsys *h);
+int mc_sgs_compute(nalu_gpu_linsys *h);
 int apply_mc_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone);
 
 }  // namespace nalu_gpu

@@ -156,36 +156,48 @@ __global__ __launch_bounds__(256) void k_lm_backward(int cnt, int w, const doubl
   zq[o + q] = tq[tpos[o + q]] - s * dinvq[o + q];
 }
 
-// Multicolour SGS ("mt_sgs"): rows of one colour are not coupled, so a sweep is one launch per
-// colour.  t and z start at zero: only colours already visited contribute, and no colour
-// comparison is needed.  Columns of regular rows are computed from the slice offsets.
+// Multicolour SGS ("mt_sgs"): rows of one colour are not coupled, so a sweep is one launch per colour, over a
+// colour-major copy of the entries that colour's rows read: those of lower colours in the forward sweep (colours
+// ascending), of higher colours in the backward sweep (descending), in the row's column order.  A colour's rows
+// are every other row or so of the matrix: read in place they would drag the whole matrix through the caches once
+// per colour and sweep (round 2: 1.2 ms per application at 256^3).
+//   forward:  t_i = (r_i - sum_{colour(c) < colour(i)} a_ic t_c) dinv_i
+//   backward: z_i = t_i - (sum_{colour(c) > colour(i)} a_ic z_c) dinv_i
 template <bool FWD>
-__global__ __launch_bounds__(256) void k_mc_sweep(SellView A, const int *__restrict__ rows, int n,
-                                                   const SolverScalars *__restrict__ sc,
-                                                   const double *__restrict__ dinv,
-                                                   const double *__restrict__ r, const double *__restrict__ t,
-                                                   double *out)
+__global__ __launch_bounds__(256) void k_mc_sweep(int cnt, int w, const double *__restrict__ av, const int *__restrict__ ac,
+                                                   const int *__restrict__ rows, const SolverScalars *__restrict__ sc,
+                                                   const double *__restrict__ dinv, const double *__restrict__ r,
+                                                   const double *__restrict__ t, double *out)
 {
   if (sc && sc->done) return;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= n) return;
+  if (q >= cnt) return;
   const int i = rows[q];
-  const int slice = i / SELL_C, lane = i % SELL_C;
-  const long long off0 = A.sliceOff[slice];
-  const long long off = off0 + lane;
-  const int w = A.sliceWidth[slice];
-  const int *kOff = A.kOff + off0 / SELL_C;
-  const bool ex = (A.exMask[(size_t)slice * 4 + (lane >> 6)] >> (lane & 63)) & 1ULL;
   double s = FWD ? r[i] : 0.0;
   for (int k = 0; k < w; ++k) {
-    const long long pos = off + (long long)k * SELL_C;
-    const int c = ex ? A.cols[pos] : i + kOff[k];
-    if (c != i && c < A.nRows) {
-      if (FWD) s -= A.vals[pos] * out[c];
-      else s += A.vals[pos] * out[c];
+    const int c = ac[(size_t)k * cnt + q];
+    if (c >= 0) {
+      if (FWD) s -= av[(size_t)k * cnt + q] * out[c];
+      else s += av[(size_t)k * cnt + q] * out[c];
     }
   }
   out[i] = FWD ? s * dinv[i] : t[i] - s * dinv[i];
+}
+
+// the matrix values of a colour's entries: entry kIdx of the row's SELL storage
+__global__ __launch_bounds__(256) void k_mc_gather_vals(int cnt, int w, const int *__restrict__ rows, const int *__restrict__ ac,
+                                                         const unsigned short *__restrict__ ak,
+                                                         const long long *__restrict__ sliceOff,
+                                                         const double *__restrict__ vals, double *__restrict__ av)
+{
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= cnt) return;
+  const int i = rows[q];
+  const long long p0 = sliceOff[i / SELL_C] + i % SELL_C;
+  for (int k = 0; k < w; ++k) {
+    const size_t idx = (size_t)k * cnt + q;
+    av[idx] = ac[idx] >= 0 ? vals[p0 + (long long)ak[idx] * SELL_C] : 0.0;
+  }
 }
 
 // ---- dataflow sweeps (schedule: sgs_flow.hpp)
@@ -1164,30 +1176,111 @@ int nalu_gpu::ensure_mc_colors(nalu_gpu_linsys *h)
   bucket_by_level(color, nc, rows, h->mcOff);
   NG_HIP(hipMalloc(&h->dMcRows, sizeof(int) * (size_t)std::max(n, 1)));
   NG_HIP(hipMemcpy(h->dMcRows, rows.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  // colour-major entries of both sweeps
+  int hostThreads = getenv("NG_HOST_THREADS") ? atoi(getenv("NG_HOST_THREADS")) : (int)std::thread::hardware_concurrency();
+  hostThreads = std::min(std::max(hostThreads, 1), 16);
+  for (int dir = 0; dir < 2; ++dir) {
+    nalu_gpu_linsys::McDir &M = h->mc[dir];
+    auto reads = [&](int i, int c) { return c != i && c < n && (dir == 0 ? color[c] < color[i] : color[c] > color[i]); };
+    M.entOff.assign((size_t)nc + 1, 0);
+    M.width.assign((size_t)std::max(nc, 1), 0);
+    for (int col = 0; col < nc; ++col) {
+      const int o = h->mcOff[col], cnt = h->mcOff[col + 1] - o;
+      const int nb = std::max(1, std::min(hostThreads, cnt / 4096));
+      std::vector<int> wb((size_t)nb, 0);
+      flow_parallel_for(nb, hostThreads, [&](int b) {
+        int w = 0;
+        for (int q = (int)((long long)cnt * b / nb); q < (int)((long long)cnt * (b + 1) / nb); ++q) {
+          const int i = rows[(size_t)(o + q)];
+          int k0 = 0;
+          for (int64_t k = h->rowPtr[i]; k < h->rowPtr[i + 1]; ++k) k0 += reads(i, h->colIdx[k]);
+          w = std::max(w, k0);
+        }
+        wb[(size_t)b] = w;
+      });
+      int w = 0;
+      for (int b = 0; b < nb; ++b) w = std::max(w, wb[(size_t)b]);
+      M.width[(size_t)col] = w;
+      M.entOff[(size_t)col + 1] = M.entOff[(size_t)col] + (long long)w * cnt;
+    }
+    M.nEnt = M.entOff[(size_t)nc];
+    FlowBuf<int> ac;
+    FlowBuf<unsigned short> ak;
+    ac.alloc((size_t)std::max<long long>(M.nEnt, 1));
+    ak.alloc((size_t)std::max<long long>(M.nEnt, 1));
+    bool wide = false;
+    for (int col = 0; col < nc; ++col) {
+      const int o = h->mcOff[col], cnt = h->mcOff[col + 1] - o, w = M.width[(size_t)col];
+      const int nb = std::max(1, std::min(hostThreads, cnt / 4096));
+      std::vector<char> wideB((size_t)nb, 0);
+      flow_parallel_for(nb, hostThreads, [&](int b) {
+        for (int q = (int)((long long)cnt * b / nb); q < (int)((long long)cnt * (b + 1) / nb); ++q) {
+          const int i = rows[(size_t)(o + q)];
+          int kk = 0;
+          for (int64_t k = h->rowPtr[i]; k < h->rowPtr[i + 1]; ++k)
+            if (reads(i, h->colIdx[k])) {
+              const size_t idx = (size_t)M.entOff[(size_t)col] + (size_t)kk * cnt + q;
+              ac[idx] = h->colIdx[k];
+              ak[idx] = (unsigned short)(k - h->rowPtr[i]);
+              if (k - h->rowPtr[i] > 65535) wideB[(size_t)b] = 1;
+              ++kk;
+            }
+          for (; kk < w; ++kk) {
+            const size_t idx = (size_t)M.entOff[(size_t)col] + (size_t)kk * cnt + q;
+            ac[idx] = -1;
+            ak[idx] = 0;
+          }
+        }
+      });
+      for (char f : wideB) wide = wide || f;
+    }
+    NG_REQUIRE(!wide, NALU_GPU_EUNSUPPORTED, "mt_sgs: a row has more than 65535 entries");
+    NG_TRY(flow_upload(ac, &M.dCol));
+    NG_TRY(flow_upload(ak, &M.dK));
+    NG_HIP(hipMalloc(&M.dVal, sizeof(double) * (size_t)std::max<long long>(M.nEnt, 1)));
+  }
   h->mcReady = true;
   return NALU_GPU_OK;
 }
 
-// z = multicolour SGS(r) on the owned rows; uses h->dT as the intermediate vector.
+// Ifpack2 compute() for mt_sgs: the current matrix values in colour-major order
+int nalu_gpu::mc_sgs_compute(nalu_gpu_linsys *h)
+{
+  NG_TRY(ensure_mc_colors(h));
+  const int nc = (int)h->mcOff.size() - 1;
+  for (const nalu_gpu_linsys::McDir &M : h->mc)
+    for (int c = 0; c < nc; ++c) {
+      const int o = h->mcOff[c], cnt = h->mcOff[c + 1] - o, w = M.width[(size_t)c];
+      if (cnt && w)
+        k_mc_gather_vals<<<(cnt + 255) / 256, 256, 0, h->stream>>>(cnt, w, h->dMcRows + o, M.dCol + M.entOff[(size_t)c],
+                                                                    M.dK + M.entOff[(size_t)c], h->dSliceOff, h->dVals,
+                                                                    M.dVal + M.entOff[(size_t)c]);
+    }
+  NG_HIP(hipGetLastError());
+  return NALU_GPU_OK;
+}
+
+// z = multicolour SGS(r) on the owned rows (mc_sgs_compute must have run for the current matrix); uses h->dT as
+// the intermediate vector.  Every row is written by its colour's launch before a later colour reads it: no zero fill.
 int nalu_gpu::apply_mc_sgs(nalu_gpu_linsys *h, const double *r, double *z, bool useDone)
 {
   NG_TRY(ensure_mc_colors(h));
-  const SellView A = sell_view(h);
   const SolverScalars *sc = useDone ? h->dScal : nullptr;
   const int nc = (int)h->mcOff.size() - 1;
-  const size_t bytes = sizeof(double) * (size_t)h->nOwned;
-  NG_HIP(hipMemsetAsync(h->dT, 0, bytes, h->stream));
-  NG_HIP(hipMemsetAsync(z, 0, bytes, h->stream));
   for (int c = 0; c < nc; ++c) {
+    const nalu_gpu_linsys::McDir &M = h->mc[0];
     const int o = h->mcOff[c], cnt = h->mcOff[c + 1] - o;
     if (cnt)
-      k_mc_sweep<true><<<(cnt + 255) / 256, 256, 0, h->stream>>>(A, h->dMcRows + o, cnt, sc, h->dDinv, r,
-                                                                 nullptr, h->dT);
+      k_mc_sweep<true><<<(cnt + 255) / 256, 256, 0, h->stream>>>(cnt, M.width[(size_t)c], M.dVal + M.entOff[(size_t)c],
+                                                                 M.dCol + M.entOff[(size_t)c], h->dMcRows + o, sc, h->dDinv,
+                                                                 r, nullptr, h->dT);
   }
   for (int c = nc - 1; c >= 0; --c) {
+    const nalu_gpu_linsys::McDir &M = h->mc[1];
     const int o = h->mcOff[c], cnt = h->mcOff[c + 1] - o;
     if (cnt)
-      k_mc_sweep<false><<<(cnt + 255) / 256, 256, 0, h->stream>>>(A, h->dMcRows + o, cnt, sc, h->dDinv,
+      k_mc_sweep<false><<<(cnt + 255) / 256, 256, 0, h->stream>>>(cnt, M.width[(size_t)c], M.dVal + M.entOff[(size_t)c],
+                                                                  M.dCol + M.entOff[(size_t)c], h->dMcRows + o, sc, h->dDinv,
                                                                   nullptr, h->dT, z);
   }
   NG_HIP(hipGetLastError());

@@ -1879,6 +1879,7 @@ static int solve_once(nalu_gpu_linsys *h, const nalu_gpu_solver_config *cfg, dou
   NG_HIP(hipGetLastError());
   NG_TRY(halo_exchange(h, h->dDinv));
   if (cfg->precond == NALU_GPU_PRECOND_SGS) NG_TRY(sgs_compute(h));
+  if (cfg->precond == NALU_GPU_PRECOND_MT_SGS) NG_TRY(mc_sgs_compute(h));
   if (cfg->precond == NALU_GPU_PRECOND_CHEBYSHEV) NG_TRY(cheb_compute(h));
   timer_end(h, NALU_GPU_T_PRECOND);
   {

@@ -1225,10 +1225,11 @@ static void cheb_apply(const orc_linsys *ls, const double *dinv, const double *r
  * tree: PARITY UNPINNED, and KokkosKernels' colouring is its own).  Here: greedy colouring in
  * row order (colour of row i = smallest colour none of its lower-numbered owned neighbours
  * has), then one SGS sweep, zero starting solution, in (colour, row) order:
- *   forward, colours ascending:   t_i = (r_i - sum_{c != i} a_ic t_c) / d_i
- *   backward, colours descending: z_i = t_i - (sum_{c != i} a_ic z_c) / d_i
- * with t and z starting at zero, so that only already-visited colours contribute (rows of
- * one colour are not coupled).  Off-rank columns are ignored as in the processor-local SGS. */
+ *   forward, colours ascending:   t_i = (r_i - sum_{colour(c) < colour(i)} a_ic t_c) / d_i
+ *   backward, colours descending: z_i = t_i - (sum_{colour(c) > colour(i)} a_ic z_c) / d_i
+ * (zero starting solution: only the colours already visited contribute; rows of one colour are
+ * not coupled; the sums in the row's column order).  Off-rank columns are ignored as in the
+ * processor-local SGS. */
 static int *g_mc_color = NULL, *g_mc_rows = NULL, *g_mc_off = NULL;
 static int g_mc_ncolors = 0;
 static int64_t g_mc_n = -1;
@@ -1280,7 +1281,7 @@ static void mc_sgs_apply(const orc_linsys *ls, const double *dinv, const double 
       double s = r[i];
       for (size_t k = g->rowPointers[i]; k < g->rowPointers[i + 1]; ++k) {
         const int c = g->colIndices[k];
-        if (c != i && c < n) s -= ls->ownedVals[k] * t[c];
+        if (c != i && c < n && g_mc_color[c] < col) s -= ls->ownedVals[k] * t[c];
       }
       t[i] = s * dinv[i];
     }
@@ -1290,7 +1291,7 @@ static void mc_sgs_apply(const orc_linsys *ls, const double *dinv, const double 
       double s = 0.0;
       for (size_t k = g->rowPointers[i]; k < g->rowPointers[i + 1]; ++k) {
         const int c = g->colIndices[k];
-        if (c != i && c < n) s += ls->ownedVals[k] * z[c];
+        if (c != i && c < n && g_mc_color[c] > col) s += ls->ownedVals[k] * z[c];
       }
       z[i] = t[i] - s * dinv[i];
     }
