@@ -34,6 +34,9 @@ bench)
   cd $R
   timeout -k 10 300 python bench.py --workload scalar > gpurun_out/r3b_bench_scalar.json 2> gpurun_out/r3b_bench_scalar.err
   echo "scalar line done"
+  timeout -k 10 300 python bench.py --workload scalar --precond sgs --cpu-n 0 > gpurun_out/r3b_bench_scalar_sgs.json 2> gpurun_out/r3b_bench_scalar_sgs.err
+  timeout -k 10 300 python bench.py --workload scalar --precond mt_sgs --cpu-n 0 > gpurun_out/r3b_bench_scalar_mt_sgs.json 2> gpurun_out/r3b_bench_scalar_mt_sgs.err
+  echo "scalar sgs / mt_sgs lines done"
   timeout -k 10 200 python bench.py --workload picard --cpu-n 0 > gpurun_out/r3b_bench_picard.json 2> gpurun_out/r3b_bench_picard.err
   echo "picard line done"
   timeout -k 10 300 python bench.py --n 512 --cpu-n 0 --no-ttt > gpurun_out/r3b_bench_512.json 2> gpurun_out/r3b_bench_512.err
