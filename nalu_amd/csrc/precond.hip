@@ -184,6 +184,62 @@ __global__ __launch_bounds__(256) void k_mc_sweep(int cnt, int w, const double *
   out[i] = FWD ? s * dinv[i] : t[i] - s * dinv[i];
 }
 
+// set-up on the device: how many entries a row reads in either sweep (the widest row of a colour sets the colour's
+// width), then the colour-major columns and entry numbers, in the row's column order
+__device__ __forceinline__ int mc_col(const SellView &A, int i, int k, long long off, const int *kOff, bool ex)
+{
+  return ex ? A.cols[off + (long long)k * SELL_C] : i + kOff[k];
+}
+
+__global__ __launch_bounds__(256) void k_mc_count(SellView A, const int *__restrict__ color, int *wF, int *wB)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.nRows) return;
+  const int slice = i / SELL_C, lane = i % SELL_C;
+  const long long off0 = A.sliceOff[slice];
+  const int *kOff = A.kOff + off0 / SELL_C;
+  const bool ex = (A.exMask[(size_t)slice * 4 + (lane >> 6)] >> (lane & 63)) & 1ULL;
+  const int ci = color[i], w = A.sliceWidth[slice];
+  int cf = 0, cb = 0;
+  for (int k = 0; k < w; ++k) {
+    const int c = mc_col(A, i, k, off0 + lane, kOff, ex);
+    if (c != i && c < A.nRows) {  // (padding: col = row)
+      cf += color[c] < ci;
+      cb += color[c] > ci;
+    }
+  }
+  // (a stale read only costs an atomic that changes nothing; without the test 16 M atomics queue on a few addresses)
+  if (cf > *(volatile int *)(wF + ci)) atomicMax(wF + ci, cf);
+  if (cb > *(volatile int *)(wB + ci)) atomicMax(wB + ci, cb);
+}
+
+template <bool FWD>
+__global__ __launch_bounds__(256) void k_mc_fill(SellView A, const int *__restrict__ color, const int *__restrict__ rows,
+                                                  int cnt, int wc, int *__restrict__ ac, unsigned short *__restrict__ ak)
+{
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= cnt) return;
+  const int i = rows[q];
+  const int slice = i / SELL_C, lane = i % SELL_C;
+  const long long off0 = A.sliceOff[slice];
+  const int *kOff = A.kOff + off0 / SELL_C;
+  const bool ex = (A.exMask[(size_t)slice * 4 + (lane >> 6)] >> (lane & 63)) & 1ULL;
+  const int ci = color[i], w = A.sliceWidth[slice];
+  int kk = 0;
+  for (int k = 0; k < w; ++k) {
+    const int c = mc_col(A, i, k, off0 + lane, kOff, ex);
+    if (c != i && c < A.nRows && (FWD ? color[c] < ci : color[c] > ci) && kk < wc) {
+      ac[(size_t)kk * cnt + q] = c;
+      ak[(size_t)kk * cnt + q] = (unsigned short)k;
+      ++kk;
+    }
+  }
+  for (; kk < wc; ++kk) {
+    ac[(size_t)kk * cnt + q] = -1;
+    ak[(size_t)kk * cnt + q] = 0;
+  }
+}
+
 // the matrix values of a colour's entries: entry kIdx of the row's SELL storage
 __global__ __launch_bounds__(256) void k_mc_gather_vals(int cnt, int w, const int *__restrict__ rows, const int *__restrict__ ac,
                                                          const unsigned short *__restrict__ ak,
@@ -1176,69 +1232,46 @@ int nalu_gpu::ensure_mc_colors(nalu_gpu_linsys *h)
   bucket_by_level(color, nc, rows, h->mcOff);
   NG_HIP(hipMalloc(&h->dMcRows, sizeof(int) * (size_t)std::max(n, 1)));
   NG_HIP(hipMemcpy(h->dMcRows, rows.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
-  // colour-major entries of both sweeps
-  int hostThreads = getenv("NG_HOST_THREADS") ? atoi(getenv("NG_HOST_THREADS")) : (int)std::thread::hardware_concurrency();
-  hostThreads = std::min(std::max(hostThreads, 1), 16);
+  // colour-major entries of both sweeps, built on the device from the SELL matrix's own columns
+  NG_REQUIRE(h->maxSliceWidth <= 65535, NALU_GPU_EUNSUPPORTED, "mt_sgs: a row has more than 65535 entries");
+  const SellView A = sell_view(h);
+  int *dColor = nullptr, *dW = nullptr;
+  NG_HIP(hipMalloc(&dColor, sizeof(int) * (size_t)std::max(n, 1)));
+  NG_HIP(hipMalloc(&dW, sizeof(int) * 2 * (size_t)std::max(nc, 1)));
+  NG_HIP(hipMemcpyAsync(dColor, color.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  NG_HIP(hipMemsetAsync(dW, 0, sizeof(int) * 2 * (size_t)std::max(nc, 1), h->stream));
+  if (n) k_mc_count<<<(n + 255) / 256, 256, 0, h->stream>>>(A, dColor, dW, dW + nc);
+  std::vector<int> wHost(2 * (size_t)std::max(nc, 1), 0);
+  NG_HIP(hipMemcpyAsync(wHost.data(), dW, sizeof(int) * 2 * (size_t)std::max(nc, 1), hipMemcpyDeviceToHost, h->stream));
+  NG_HIP(hipStreamSynchronize(h->stream));
   for (int dir = 0; dir < 2; ++dir) {
     nalu_gpu_linsys::McDir &M = h->mc[dir];
-    auto reads = [&](int i, int c) { return c != i && c < n && (dir == 0 ? color[c] < color[i] : color[c] > color[i]); };
     M.entOff.assign((size_t)nc + 1, 0);
     M.width.assign((size_t)std::max(nc, 1), 0);
     for (int col = 0; col < nc; ++col) {
-      const int o = h->mcOff[col], cnt = h->mcOff[col + 1] - o;
-      const int nb = std::max(1, std::min(hostThreads, cnt / 4096));
-      std::vector<int> wb((size_t)nb, 0);
-      flow_parallel_for(nb, hostThreads, [&](int b) {
-        int w = 0;
-        for (int q = (int)((long long)cnt * b / nb); q < (int)((long long)cnt * (b + 1) / nb); ++q) {
-          const int i = rows[(size_t)(o + q)];
-          int k0 = 0;
-          for (int64_t k = h->rowPtr[i]; k < h->rowPtr[i + 1]; ++k) k0 += reads(i, h->colIdx[k]);
-          w = std::max(w, k0);
-        }
-        wb[(size_t)b] = w;
-      });
-      int w = 0;
-      for (int b = 0; b < nb; ++b) w = std::max(w, wb[(size_t)b]);
-      M.width[(size_t)col] = w;
-      M.entOff[(size_t)col + 1] = M.entOff[(size_t)col] + (long long)w * cnt;
+      M.width[(size_t)col] = wHost[(size_t)dir * nc + col];
+      M.entOff[(size_t)col + 1] = M.entOff[(size_t)col] + (long long)M.width[(size_t)col] * (h->mcOff[col + 1] - h->mcOff[col]);
     }
     M.nEnt = M.entOff[(size_t)nc];
-    FlowBuf<int> ac;
-    FlowBuf<unsigned short> ak;
-    ac.alloc((size_t)std::max<long long>(M.nEnt, 1));
-    ak.alloc((size_t)std::max<long long>(M.nEnt, 1));
-    bool wide = false;
+    const size_t ne = (size_t)std::max<long long>(M.nEnt, 1);
+    NG_HIP(hipMalloc(&M.dCol, sizeof(int) * ne));
+    NG_HIP(hipMalloc(&M.dK, sizeof(unsigned short) * ne));
+    NG_HIP(hipMalloc(&M.dVal, sizeof(double) * ne));
     for (int col = 0; col < nc; ++col) {
       const int o = h->mcOff[col], cnt = h->mcOff[col + 1] - o, w = M.width[(size_t)col];
-      const int nb = std::max(1, std::min(hostThreads, cnt / 4096));
-      std::vector<char> wideB((size_t)nb, 0);
-      flow_parallel_for(nb, hostThreads, [&](int b) {
-        for (int q = (int)((long long)cnt * b / nb); q < (int)((long long)cnt * (b + 1) / nb); ++q) {
-          const int i = rows[(size_t)(o + q)];
-          int kk = 0;
-          for (int64_t k = h->rowPtr[i]; k < h->rowPtr[i + 1]; ++k)
-            if (reads(i, h->colIdx[k])) {
-              const size_t idx = (size_t)M.entOff[(size_t)col] + (size_t)kk * cnt + q;
-              ac[idx] = h->colIdx[k];
-              ak[idx] = (unsigned short)(k - h->rowPtr[i]);
-              if (k - h->rowPtr[i] > 65535) wideB[(size_t)b] = 1;
-              ++kk;
-            }
-          for (; kk < w; ++kk) {
-            const size_t idx = (size_t)M.entOff[(size_t)col] + (size_t)kk * cnt + q;
-            ac[idx] = -1;
-            ak[idx] = 0;
-          }
-        }
-      });
-      for (char f : wideB) wide = wide || f;
+      if (!cnt || !w) continue;
+      if (dir == 0)
+        k_mc_fill<true><<<(cnt + 255) / 256, 256, 0, h->stream>>>(A, dColor, h->dMcRows + o, cnt, w, M.dCol + M.entOff[(size_t)col],
+                                                                  M.dK + M.entOff[(size_t)col]);
+      else
+        k_mc_fill<false><<<(cnt + 255) / 256, 256, 0, h->stream>>>(A, dColor, h->dMcRows + o, cnt, w, M.dCol + M.entOff[(size_t)col],
+                                                                   M.dK + M.entOff[(size_t)col]);
     }
-    NG_REQUIRE(!wide, NALU_GPU_EUNSUPPORTED, "mt_sgs: a row has more than 65535 entries");
-    NG_TRY(flow_upload(ac, &M.dCol));
-    NG_TRY(flow_upload(ak, &M.dK));
-    NG_HIP(hipMalloc(&M.dVal, sizeof(double) * (size_t)std::max<long long>(M.nEnt, 1)));
   }
+  NG_HIP(hipGetLastError());
+  NG_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(dColor);
+  (void)hipFree(dW);
   h->mcReady = true;
   return NALU_GPU_OK;
 }
