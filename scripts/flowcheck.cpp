@@ -162,6 +162,22 @@ int main()
   bad += check("random 3000 chunk 256", random_graph(3000, 12, rng), 256, 8, 8);
   bad += check("tiny 1", lattice(1, 1, 1, rng), 1024, 8, 8);
   bad += check("line 300", lattice(300, 1, 1, rng), 128, 8, 8);
+  {  // a row whose columns are not ascending: the schedule locates an entry's value by its position after the
+     // row's first dependency, so such a graph must be refused (the library then runs the level launches)
+    Csr A = lattice(12, 6, 5, rng);
+    const int i = 200;
+    std::swap(A.col[(size_t)A.rowPtr[i]], A.col[(size_t)A.rowPtr[i] + 4]);  // (a lower and an upper entry trade places)
+    FlowBuf<int> chunkOf;
+    FlowTiling T = flow_chunking(A.n, A.rowPtr.data(), A.col.data(), 256, 0, 0, chunkOf, 2);
+    int refused = 0;
+    for (int dir = 0; dir < 2; ++dir) {
+      FlowSchedule S;
+      const std::string why = flow_build(A.n, A.rowPtr.data(), A.col.data(), chunkOf, T.nChunks, dir == 0, S, 2);
+      refused += !why.empty();
+      printf("unsorted row           %s: %s\n", dir == 0 ? "fwd" : "bwd", why.empty() ? "accepted" : why.c_str());
+    }
+    bad += refused == 0;
+  }
   printf(bad ? "FAILED\n" : "all schedules replay the sequential sweeps bit for bit\n");
   return bad != 0;
 }

@@ -16,3 +16,4 @@ def test_schedule_replays_the_sequential_sweeps(tmp_path):
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "all schedules replay the sequential sweeps bit for bit" in out, out
     assert out.count("tiled chunks") >= 6 and out.count("contiguous chunks") >= 6, out
+    assert "are not consecutive" in out, out  # a row with unsorted columns is refused, not mis-scheduled
