@@ -820,8 +820,10 @@ __global__ __launch_bounds__(SELL_C, 2) void k_assemble_rows_march(SellView A, t
 // kDppArea: the area vector of the edge to the lane below is that lane's edge to the lane above, shifted in
 // instead of loaded (continuity: 1.016 -> 0.985 ms at 256^3; the scalar operator's 4-double edges then spill:
 // 1.26 -> 1.37 ms); stores are nontemporal for both (-1.5 %: the written lines are not read again)
-template <class Op> struct LagCfg { static constexpr bool kDefault = true, kDppArea = true; };
-template <> struct LagCfg<ScalOp> { static constexpr bool kDefault = true, kDppArea = false; };
+// (kYShare: which y-share form of the prefetching kernel the operator takes -- 1: two share buffers per wave, 1.5 KiB
+// of LDS more per wave; 2: one buffer and a second barrier, for the scalar operator's 80 KiB workgroups)
+template <class Op> struct LagCfg { static constexpr bool kDefault = true, kDppArea = true; static constexpr int kYShare = 1; };
+template <> struct LagCfg<ScalOp> { static constexpr bool kDefault = true, kDppArea = false; static constexpr int kYShare = 2; };
 // (development aids: ablations of the lagged kernel, never built into the shipped library)
 #ifdef NG_LAG_NOFLUX
 template <class Op>
@@ -1107,7 +1109,18 @@ template <class Op, int GY> struct PfLayout {
   __host__ __device__ static constexpr int slot(int k) { return k < 2 ? k : k + 1; }
 };
 
-template <class Op, bool SET, int GY>
+// YS (GY = 4; the default since the end of round 3, NG_ASM_LAG_YSHARE=0 turns it off: 256^3 continuity 0.88 -> 0.84 ms,
+// scalar 1.10 -> 1.08 ms): an edge between two lines of a group is evaluated ONCE, by the upper line's wave as
+// its slot 1; the lower line's shares (the R-row entries of the same evaluation: lhs[2], lhs[3], rhs[1], bit for bit
+// what its own mirrored evaluation gives -- the invariance the lagged z edge already rests on) travel through a
+// double-buffered LDS slot and are added one step later, in their place of the row's CSR-ordered sums (behind
+// slots 0-3, before the z edge above).  17 instead of 20 edge evaluations per group and step; the receiving waves
+// need neither the upper line's row nor the edge data of their slot 4 (whose LDS region is one of the two buffers).
+// YS = 1: two buffers (the step's parity), one barrier per step: written in step t behind the barrier, read in step
+// t + 1 behind the next.  YS = 2: ONE buffer (the slot-4 region: no LDS beyond the plain kernel's) and a second
+// barrier right behind the first: the receivers take their shares between the two, the writers write behind the
+// second (the waves have just met at the first barrier: the second one finds no stragglers).
+template <class Op, bool SET, int GY, int YS = 0>
 __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_assemble_rows_lagpf(SellView A, typename Op::Params P,
                                                                   double *__restrict__ rhs,
                                                                   const int *__restrict__ list, int nItems,
@@ -1122,7 +1135,10 @@ __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_
   static_assert(GY == 1 || GY == 4 || GY == 8, "a group is one line per wave");
   constexpr int NW = GY > 1 ? GY : SELL_C / 64;  // waves per workgroup
   constexpr int QS = SELL_C / 64;                // quarters per slice: a group is QS consecutive items
-  __shared__ double ldsAll[NW * L::kDoubles];
+  static_assert(!YS || GY == 4, "y-share: groups of four lines");
+  constexpr int SH = 3 * 64;  // a share buffer: three doubles per lane
+  static_assert(!YS || NEF * 64 >= SH, "the slot-4 edge region holds one share buffer");
+  __shared__ double ldsAll[NW * L::kDoubles + (YS == 1 ? NW * SH : 0)];
   // The workgroups behind the last item take the slices outside the runs (the mesh's boundary planes and lines) in
   // their burst form, one slice each: in the same launch they fill the CUs that the last runs leave one by one,
   // instead of waiting for the whole grid to drain (a launch of their own: 26 of 875 us at 256^3).
@@ -1139,7 +1155,7 @@ __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_
   // (GY > 1: a group may have fewer than GY lines: run index -1; such a wave only keeps the barriers company)
   const int ridx = GY > 1 ? list[gBase + wv] : (list ? list[item] : item);
   if (GY > 1 && ridx < 0) {
-    const int n = A.march[list[gBase]].len;
+    const int n = A.march[list[gBase]].len * (YS == 2 ? 2 : 1) + (YS ? 1 : 0);
     for (int t = 0; t < n; ++t) __syncthreads();
     return;
   }
@@ -1223,13 +1239,32 @@ __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_
       const int g0 = 2 * i, g1 = 2 * i + 1;
       const long long id = (long long)((half ? pfId[g1 / NEF] : pfId[g0 / NEF]) & 0x7FFFFFFFu) + l2;
       const double *src = (half ? Op::edge_field(P, g1 % NEF) : Op::edge_field(P, g0 % NEF)) + id;
-      if (id + 1 < nEdges)
+      // (y-share: a receiving wave's slot-4 region is a share buffer, and it has no use for those edges)
+      const bool shareRegion = YS && !farP && (half ? g1 / NEF : g0 / NEF) == NS - 1;
+      if (id + 1 < nEdges && !shareRegion)
         __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(ldsE + i * 128), 16, 0, 0);
+    }
+  };
+  double pDiag = 0.0, pRhs = 0.0;  // the sums of the last step's row, complete but for its last edge(s)
+  // (y-share) the two share buffers of wave v: its slot-4 edge region and its slot behind the waves' regions
+  auto share_buf = [&](int v, int parity) {
+    return YS == 1 && parity ? ldsAll + NW * L::kDoubles + v * SH
+                             : ldsAll + v * L::kDoubles + L::NB * NFP * 64 + (NS - 1) * NEF * 64;
+  };
+  // the receiving wave's slot 4 of the last step: behind slots 0-3 in the row's sums, before the z edge above
+  auto take_share = [&](int parity, long long posRow) {
+    if (!farP && (act & 16u)) {
+      const double *sh = share_buf(wv, parity);
+      const double s2 = sh[lane], s3 = sh[64 + lane], sr = sh[128 + lane];
+      pDiag += s3;
+      pRhs += sr;
+      const long long pos = posRow + kk(4) * SELL_C;
+      if (SET) LAG_ST(A.vals + pos, s2);
+      else A.vals[pos] += s2;
     }
   };
   prefetch(rowW, 0);
   Node prev;
-  double pDiag = 0.0, pRhs = 0.0;
   if (act & 1u) prev = Op::load(P, row + D.ko[0]);
   // (B) the loads that hit the L2 -- far rows, the end lanes' x neighbours, the first lane's edge to the lane
   // below -- are issued at the END of the previous step, into registers that step no longer needs
@@ -1328,6 +1363,7 @@ __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_
     }
     if (t > 0) {
       const long long posP = pos0 - gOffStep;
+      if (YS) take_share(YS == 1 ? (t - 1) & 1 : 0, posP);  // the last step's slot 4, evaluated by the wave above
       if (act & 32u) {
         pDiag += lhs[3];
         pRhs += rh[1];
@@ -1342,6 +1378,10 @@ __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_
       }
       if (SET) LAG_ST(rhs + row - gRowStep, pRhs);
       else rhs[row - gRowStep] += pRhs;
+    }
+    if (YS == 2) {  // the one share buffer: read in front of this barrier, written behind it
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the shares are in registers
+      __syncthreads();
     }
     auto slot = [&](int e, const Node &nb) {
       if ((act >> e) & 1u) {
@@ -1382,7 +1422,15 @@ __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_
       }
     }
     if (GY == 1) slot(1, ym);
-    else if (!farM) slot(1, group_row(wv - 1));
+    else if (!farM) {
+      slot(1, group_row(wv - 1));
+      if (YS && (act & 2u)) {  // the lower line's shares of this edge: its slot 4 of this step
+        double *sh = share_buf(wv - 1, t & 1);
+        sh[lane] = lhs[2];
+        sh[64 + lane] = lhs[3];
+        sh[128 + lane] = rh[1];
+      }
+    }
     {
       Node xm;
       const double *po = reinterpret_cast<const double *>(&own), *pe = reinterpret_cast<const double *>(&en);
@@ -1402,7 +1450,7 @@ __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_
     if (GY == 1) slot(4, yp);
     else if (early4) {
       if (act & 16u) { diag += d4; b += r4; }
-    } else if (!farP) slot(4, group_row(wv + 1));  // (farM && farP: no such group, finalize keeps single lines out)
+    } else if (!farP && !YS) slot(4, group_row(wv + 1));  // (farM && farP: no such group, finalize keeps single lines out)
     if (SET) {
       for (int k = 0; k < w; ++k)
         if ((zeroMask >> k) & 1u) A.vals[pos0 + (long long)k * SELL_C] = 0.0;
@@ -1418,6 +1466,10 @@ __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_
       pos0 += gOffStep;
       loadB();
     }
+  }
+  if (YS) {  // the last step's slot 4 of the receiving waves
+    __syncthreads();
+    take_share((gLen - 1) & 1, pos0);
   }
   if (act & 32u) {
     double lhs[4], rh[2];
@@ -1668,7 +1720,15 @@ int assemble(nalu_gpu_linsys *h, const typename Op::Params &P, int mode)
             else k_assemble_rows_lagpf<Op, false, 8><<<nI, 512, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges, 0);
           } else {
             const int nT = env_not_zero("NG_ASM_LAG_TAIL") ? nRest : 0;  // (NG_ASM_LAG_TAIL=0: the burst kernel in a launch of its own)
-            if (set) k_assemble_rows_lagpf<Op, true, 4><<<nI + nT, 256, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges, nPat);
+            bool launched = false;
+            if (env_not_zero("NG_ASM_LAG_YSHARE")) {  // (the default; NG_ASM_LAG_YSHARE=0: every wave evaluates its own slot 4)
+              constexpr int YS = LagCfg<Op>::kYShare;
+              if (set) k_assemble_rows_lagpf<Op, true, 4, YS><<<nI + nT, 256, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges, nPat);
+              else k_assemble_rows_lagpf<Op, false, 4, YS><<<nI + nT, 256, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges, nPat);
+              launched = true;
+            }
+            if (launched) {
+            } else if (set) k_assemble_rows_lagpf<Op, true, 4><<<nI + nT, 256, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges, nPat);
             else k_assemble_rows_lagpf<Op, false, 4><<<nI + nT, 256, 0, h->stream>>>(sell_view_all(h), P, h->dRhs, h->dMarchGroupsP, nI, h->nEdges, nPat);
             restDone = nT == nRest;
           }

@@ -144,7 +144,7 @@ SLOT_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", ["default", "row", "NG_ASM_BURST", "NG_ASM_MARCH", "lag_off", "lag_nopf", "lag_groups", "lag_pf", "lag_pf_groups8"])
+@pytest.mark.parametrize("variant", ["default", "row", "NG_ASM_BURST", "NG_ASM_MARCH", "lag_off", "lag_nopf", "lag_groups", "lag_pf", "lag_pf_groups8", "lag_pf_noyshare"])
 @pytest.mark.parametrize("dims,perturb,min_computed", SLOT_CASES)
 def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, perturb, min_computed, variant):
     """default: the automatic choice (the marching kernel where at least half of the slices are in
@@ -165,6 +165,8 @@ def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, pert
         monkeypatch.setenv("NG_ASM_LAG_GROUPS", "0")
     elif variant == "lag_pf_groups8":  # the default kernel on groups of eight lines (512-thread workgroups) instead of four
         monkeypatch.setenv("NG_ASM_LAG_GY", "8")
+    elif variant == "lag_pf_noyshare":  # every wave evaluates its own slot 4 (the default hands the shares of an edge
+        monkeypatch.setenv("NG_ASM_LAG_YSHARE", "0")  # between two lines of a group down through LDS: one evaluation)
     elif variant != "default":
         monkeypatch.setenv(variant, "1")
     c = BenchCase(G, oracle, dims, perturb)
@@ -181,7 +183,8 @@ def test_slot_major_assembly_bit_exact(G, torch, oracle, monkeypatch, dims, pert
                                       "NG_ASM_MARCH": lagpf, "lag_off": 4 if marching else 0,
                                       "lag_nopf": lag if marching else 0, "lag_groups": lag if marching else 0,
                                       "lag_pf": lagpf if marching else 0,
-                                      "lag_pf_groups8": lagpf if marching else 0}[variant], li
+                                      "lag_pf_groups8": lagpf if marching else 0,
+                                      "lag_pf_noyshare": lagpf if marching else 0}[variant], li
     if dims == (256, 6, 40):  # 4 interior lines x 38 interior planes: runs of 32 + 6 slices
         assert marching and li["march_longest"] == 32 and li["march_slices"] == 152 and li["march_runs"] == 8, li
     if dims == (512, 6, 40):  # ... two slices per line
