@@ -141,6 +141,7 @@ SLOT_CASES = [
     ((256, 13, 7), 0.125, 0.9),   # 11 interior lines: groups of 4 + 4 + 3 (or 8 + 3) adjacent lines
     ((256, 7, 5), 0.125, 0.9),    # 5 interior lines: a group of four and ONE line left over (the kernel's single-run form)
     ((256, 3, 6), 0.125, 0.9),    # 1 interior line per plane: no groups at all
+    ((256, 8, 6), 0.125, 0.9),    # 6 interior lines: a group of four and a group of TWO (each wave an end of its group)
 ]
 
 
