@@ -1412,7 +1412,11 @@ __global__ __launch_bounds__(GY > 1 ? 64 * GY : SELL_C, GY == 8 ? 1 : 2) void k_
       if (t + 1 < gLen && (act & 2u)) ym = LAG_FAR(row + gRowStep + D.ko[1]);
     } else if (early4) {
       if (act & 16u) {
+#ifdef NG_LAG_NOFAREDGE  // (ablation, timing only: the last wave of a group without its fifth evaluation)
+        lhs[0] = own.x[0]; lhs[1] = ym.x[0]; rh[0] = E[4].av[0];
+#else
         LAG_EDGE(P, Op::mirrored(E[4], (eid[4] >> 31) != 0), own, ym, lhs, rh);
+#endif
         d4 = lhs[0];
         r4 = rh[0];
         const long long pos = pos0 + kk(4) * SELL_C;
